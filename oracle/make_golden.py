@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own functions.
+
+Runs only in the build container (needs /root/reference).  Nothing from the
+reference is copied: each function is pulled out of its script with ``ast``
+(the scripts run whole simulations at import, so they cannot be imported),
+executed on seeded inputs, and only the numeric inputs/outputs are saved.
+
+    python oracle/make_golden.py            # rewrites tests/golden/
+
+Fixtures (inputs are stored as complex64 so GPU and reference see identical
+values; reference outputs are complex128):
+  csa_<naz>x<nrg>.npz      sar_focus_csa   (sar_ati_dcpa_sim_csa.py:202-396)
+  csa_refconst_*.npz       same, literal reference radar constants (partial chirp)
+  csa_digest_1024.npz      1024x1024: peak, sampled rows/cols, norms only
+  ati_128x128.npz          two-channel scene -> slc1, slc2 + the literal
+                           expressions of :414-419,447-449 and viewer :249-250
+  echo_mono.npz            run_physics_engine        (sar_satellite_sim.py:211-305)
+  echo_bistatic.npz        run_bistatic_physics_gpu  (sar_ati_dcpa_sim_csa.py:106-181)
+"""
+import ast
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("SARX_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import csa_oracle as orc  # noqa: E402
+
+
+def extract(script, name, env):
+    """Compile one top-level ``def`` of a reference script into ``env``."""
+    path = os.path.join(REF, script)
+    with open(path) as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, path, "exec"), env)
+            return env[name]
+    raise KeyError(f"{name} not found in {script}")
+
+
+def quiet(fn, *a, **kw):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_focus = extract("sar_ati_dcpa_sim_csa.py", "sar_focus_csa", {"np": np})
+
+    def save_csa(tag, raw64, k):
+        args = orc.focus_args(k)
+        img_t, rax, cax = ref_focus(raw64.astype(np.complex128), *args)
+        np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), phist=raw64, args=np.array(args, dtype=np.float64),
+                 img_T=np.ascontiguousarray(img_t), range_axis=rax, cross_range_axis=cax)
+        peak = np.abs(img_t).max() / np.abs(img_t).mean()
+        print(f"{tag}: out {img_t.shape} peak/mean {peak:.1f}")
+
+    # focused point-target scenes, pulse shortened to fit the window
+    for (naz, nrg, seed, cl) in [(64, 64, 1, None), (96, 80, 2, None), (128, 128, 3, -20.0),
+                                 (256, 256, 4, -20.0), (128, 512, 5, None), (512, 128, 6, None)]:
+        raw, k = orc.point_scene(naz, nrg, seed=seed, clutter_db=cl)
+        save_csa(f"csa_{naz}x{nrg}", raw, k)
+
+    # literal reference constants (20 us pulse: only part of the chirp is in the window)
+    k = orc.reference_radar_constants()
+    k["t_start_fast"] = 2 * k["R0"] / k["C"] - k["T_p"] / 2 - 1e-6      # sar_ati_dcpa_sim_csa.py:112
+    rng = np.random.default_rng(7)
+    raw = (rng.standard_normal((128, 256)) + 1j * rng.standard_normal((128, 256))).astype(np.complex64)
+    save_csa("csa_refconst_128x256", raw, k)
+
+    # 1024^2 digest
+    raw, k = orc.point_scene(1024, 1024, seed=11, clutter_db=-20.0)
+    img_t, rax, cax = ref_focus(raw.astype(np.complex128), *orc.focus_args(k))
+    mag = np.abs(img_t)
+    pk = np.unravel_index(np.argmax(mag), mag.shape)
+    rows = np.array([0, 1, 127, 300, 511, 512, 777, 1023])
+    np.savez_compressed(os.path.join(OUT, "csa_digest_1024.npz"), seed=11, clutter_db=-20.0,
+             args=np.array(orc.focus_args(k)), peak_index=np.array(pk), peak_value=img_t[pk],
+             rows=rows, row_values=img_t[rows, :], col_values=np.ascontiguousarray(img_t[:, rows]),
+             l2=np.linalg.norm(img_t), sum=img_t.sum(), range_axis=rax, cross_range_axis=cax)
+    print("csa_digest_1024: peak", pk, abs(img_t[pk]))
+
+    # two-channel scene -> ATI/DPCA literal expressions
+    (r1, r2), k = orc.point_scene(128, 128, seed=21, clutter_db=-25.0, two_channel=True)
+    slc1, rax, cax = ref_focus(r1.astype(np.complex128), *orc.focus_args(k))
+    slc2, _, _ = ref_focus(r2.astype(np.complex128), *orc.focus_args(k))
+    ati_interf = slc1 * np.conj(slc2)                       # :414
+    ati_phase = np.angle(ati_interf)                        # :415
+    slc1_mag = np.abs(slc1)                                 # :416
+    dpca_mag = np.abs(slc1 - slc2)                          # :418-419
+    mag_mask = np.abs(slc1) > (np.max(np.abs(slc1)) * 0.05)  # :447
+    ati_phase_masked = np.copy(ati_phase)
+    ati_phase_masked[~mag_mask] = 0                         # :448-449
+    cal_phase = np.angle(np.mean(slc1 * np.conj(slc2)))     # viewer :249-250
+    np.savez_compressed(os.path.join(OUT, "ati_128x128.npz"), raw1=r1, raw2=r2, args=np.array(orc.focus_args(k)),
+             slc1=np.ascontiguousarray(slc1), slc2=np.ascontiguousarray(slc2), ati_phase=ati_phase,
+             slc1_mag=slc1_mag, dpca_mag=dpca_mag, mask=mag_mask, ati_phase_masked=ati_phase_masked,
+             cal_phase=cal_phase)
+    print("ati_128x128: cal_phase", cal_phase, "mask px", int(mag_mask.sum()))
+
+    # echo generators, tiny, with scaled module constants injected as globals
+    kk = orc.reference_radar_constants()
+    fs_small = 6e6                       # int(22e-6*FS) -> 132 samples
+    tgts = [{"position": np.array([30.0, -40.0, 0.0]), "rcs": 10.0},
+            {"position": np.array([-80.0, 25.0, 5.0]), "rcs": 250.0}]
+    t_vec = np.linspace(-0.01, 0.01, 24)
+    pos_tx, vel_tx = orc.orbit_track(t_vec, kk)
+    env = {"np": np, "BW": 5e6, "T_p": kk["T_p"], "R0": kk["R0"], "C": kk["C"], "FC": kk["FC"]}
+    mono = extract("sar_satellite_sim.py", "run_physics_engine", env)
+    # the reference hard-codes fs = 600e6 inside (:245): window is 13200 samples
+    raw_m, t0_m, fs_m = quiet(mono, tgts, pos_tx[:3], t_vec[:3])
+    np.savez_compressed(os.path.join(OUT, "echo_mono.npz"), raw=raw_m.astype(np.complex128), t_start_fast=t0_m, fs=fs_m,
+             pos_sat=pos_tx[:3], tgt_pos=np.array([t["position"] for t in tgts]),
+             tgt_rcs=np.array([t["rcs"] for t in tgts]), BW=5e6, T_p=kk["T_p"], FC=kk["FC"])
+    print("echo_mono:", raw_m.shape, np.abs(raw_m).max())
+    try:
+        import torch
+        env = {"np": np, "torch": torch, "device": torch.device("cpu"), "FS": fs_small, "BW": 5e6,
+               "T_p": kk["T_p"], "R0": kk["R0"], "C": kk["C"], "FC": kk["FC"]}
+        bist = extract("sar_ati_dcpa_sim_csa.py", "run_bistatic_physics_gpu", env)
+        raw_b, t0_b = quiet(bist, tgts, t_vec, pos_tx, vel_tx, -kk["d_rx"] / 2, np.array([15.0, 0.0, 0.0]))
+        np.savez_compressed(os.path.join(OUT, "echo_bistatic.npz"), raw=raw_b, t_start_fast=t0_b, fs=fs_small,
+                 t_vec=t_vec, pos_tx=pos_tx, vel_tx=vel_tx, rx_offset=-kk["d_rx"] / 2,
+                 vel_target=np.array([15.0, 0.0, 0.0]), tgt_pos=np.array([t["position"] for t in tgts]),
+                 tgt_rcs=np.array([t["rcs"] for t in tgts]), BW=5e6, T_p=kk["T_p"], FC=kk["FC"])
+        print("echo_bistatic:", raw_b.shape, np.abs(raw_b).max())
+    except ImportError:
+        print("torch missing: echo_bistatic.npz not regenerated")
+
+
+if __name__ == "__main__":
+    main()

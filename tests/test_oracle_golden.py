@@ -1,0 +1,85 @@
+"""Pin the CPU oracle to the reference: every fixture under tests/golden was
+produced by the reference's own functions (oracle/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import csa_oracle as orc
+from conftest import load_golden
+
+CSA_FIXTURES = ["csa_64x64", "csa_96x80", "csa_128x128", "csa_256x256", "csa_128x512", "csa_512x128",
+                "csa_refconst_128x256"]
+
+
+@pytest.mark.parametrize("tag", CSA_FIXTURES)
+def test_focus_matches_reference(tag):
+    g = load_golden(tag + ".npz")
+    img_t, rax, cax = orc.sar_focus_csa(g["phist"], *g["args"])
+    assert img_t.shape == g["img_T"].shape
+    assert orc.rel_l2(img_t, g["img_T"]) < 1e-12
+    np.testing.assert_allclose(rax, g["range_axis"], rtol=1e-15)
+    np.testing.assert_allclose(cax, g["cross_range_axis"], rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["csa_96x80", "csa_256x256", "csa_refconst_128x256"])
+def test_lean_path_equals_literal(tag):
+    g = load_golden(tag + ".npz")
+    a = orc.sar_focus_csa(g["phist"], *g["args"])[0]
+    b = orc.sar_focus_csa_lean(g["phist"], *g["args"], block=40)[0]
+    assert orc.rel_l2(b, a) < 1e-12
+    assert orc.rel_l2(b, g["img_T"]) < 1e-12
+
+
+def test_stages_are_consistent():
+    g = load_golden("csa_128x128.npz")
+    img_t, _, _, (s1, s2, s3, s4) = orc.sar_focus_csa(g["phist"], *g["args"], return_stages=True)
+    assert orc.rel_l2(s4.T, g["img_T"]) < 1e-12
+    # stage 3 -> 4 is a plain inverse FFT along azimuth in natural order
+    assert orc.rel_l2(np.fft.ifft(s3, axis=0), s4) < 1e-13
+    assert s1.shape == s2.shape == s3.shape == (128, 128)
+
+
+def test_digest_1024():
+    g = load_golden("csa_digest_1024.npz")
+    raw, k = orc.point_scene(1024, 1024, seed=int(g["seed"]), clutter_db=float(g["clutter_db"]))
+    np.testing.assert_array_equal(np.array(orc.focus_args(k)), g["args"])
+    img_t, rax, cax = orc.sar_focus_csa_lean(raw, *g["args"])
+    pk = np.unravel_index(np.argmax(np.abs(img_t)), img_t.shape)
+    assert tuple(pk) == tuple(g["peak_index"])
+    assert abs(img_t[pk] - g["peak_value"]) < 1e-9 * abs(g["peak_value"])
+    assert orc.rel_l2(img_t[g["rows"], :], g["row_values"]) < 1e-12
+    assert orc.rel_l2(img_t[:, g["rows"]], g["col_values"]) < 1e-12
+    assert abs(np.linalg.norm(img_t) - g["l2"]) < 1e-10 * g["l2"]
+
+
+def test_ati_dpca_products():
+    g = load_golden("ati_128x128.npz")
+    p = orc.ati_dpca(g["slc1"], g["slc2"], mask_frac=0.05, cal_phase=0.0)
+    np.testing.assert_allclose(p["ati_phase"], g["ati_phase"], atol=1e-12)
+    np.testing.assert_allclose(p["slc1_mag"], g["slc1_mag"], rtol=1e-14)
+    np.testing.assert_allclose(p["dpca_mag"], g["dpca_mag"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_array_equal(p["mask"], g["mask"])
+    np.testing.assert_allclose(p["ati_phase_masked"], g["ati_phase_masked"], atol=1e-12)
+    assert abs(orc.phase_balance(g["slc1"], g["slc2"]) - float(g["cal_phase"])) < 1e-12
+    # focusing the fixture's raw channels reproduces its SLCs
+    s1 = orc.sar_focus_csa(g["raw1"], *g["args"])[0]
+    assert orc.rel_l2(s1, g["slc1"]) < 1e-12
+
+
+def test_echo_models_match_reference():
+    g = load_golden("echo_mono.npz")
+    tg = [{"position": p, "rcs": r} for p, r in zip(g["tgt_pos"], g["tgt_rcs"])]
+    raw = orc.echo_monostatic(tg, g["pos_sat"], g["raw"].shape[1], float(g["fs"]), float(g["t_start_fast"]),
+                              float(g["FC"]), float(g["BW"]) / float(g["T_p"]), float(g["T_p"]))
+    assert orc.rel_l2(raw, g["raw"]) < 1e-9      # phases ~3e8 rad: fp64 ulp there is 6e-8
+    g = load_golden("echo_bistatic.npz")
+    tg = [{"position": p, "rcs": r} for p, r in zip(g["tgt_pos"], g["tgt_rcs"])]
+    raw = orc.echo_bistatic(tg, g["t_vec"], g["pos_tx"], g["vel_tx"], float(g["rx_offset"]), g["vel_target"],
+                            g["raw"].shape[1], float(g["fs"]), float(g["t_start_fast"]), float(g["FC"]),
+                            float(g["BW"]) / float(g["T_p"]), float(g["T_p"]))
+    assert orc.rel_l2(raw, g["raw"]) < 1e-6
+
+
+def test_reference_constants():
+    k = orc.reference_radar_constants()
+    assert abs(k["V_sat"] - 7701.0) < 5 and abs(k["R0"] - 509.4e3) < 200
+    assert abs(k["d_rx"] - 2.567) < 2e-3 and abs(k["Kr"] - 2.5e13) < 1.0
