@@ -1,0 +1,526 @@
+// libsarx C ABI (include/sarx.h): context, CSA plan (fp64 migration tables,
+// twiddles, scratch), pass orchestration, ATI/DPCA, RCCL all-gather.
+#include "../../include/sarx.h"
+#include "csa_kernels.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sarx;
+
+static thread_local std::string g_init_error;
+static constexpr double C_LIGHT = 299792458.0;     // sar_ati_dcpa_sim_csa.py:211
+static constexpr int N_EVENTS = 64;
+static constexpr int TW_MAX = 16384;
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static bool load_rccl(std::string& err) {
+    if (g_rccl.lib) return true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { err = std::string("dlopen librccl: ") + dlerror(); return false; }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        err = "librccl lacks a required symbol";
+        dlclose(h);
+        return false;
+    }
+    g_rccl.lib = h;
+    return true;
+}
+
+struct sarx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev[N_EVENTS] = {};
+    bool ev_set[N_EVENTS] = {};
+    hipEvent_t comm_fence = nullptr;
+    float2* tw_all = nullptr;          // table for size n at offset n: exp(-2 pi i m/n)
+    float* ati_part_max = nullptr;     // reduction scratch
+    double2* ati_part_sum = nullptr;
+    double* ati_out3 = nullptr;
+    ncclComm_t comm = nullptr;
+    int n_ranks = 0, rank = 0;
+    std::string err;
+};
+
+struct sarx_plan {
+    sarx_ctx* ctx = nullptr;
+    int n_az = 0, n_rg = 0;
+    unsigned flags = 0;
+    sarx_radar_params p{};
+    int az_s = 0;          // four-step split: n_az = (n_az/az_s) * az_s; az_s == n_az means single step
+    int az_w = 32;         // azimuth tile width (range samples)
+    double2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr;
+    float2* buf_b = nullptr;           // scratch image
+    float2* buf_a = nullptr;           // second scratch (RG_MAJOR only)
+    float2 *h_in = nullptr, *h_out = nullptr;   // device staging for the *_host entry point
+    uint64_t bytes = 0;
+};
+
+static int fail(sarx_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_init_error = buf;
+    return code;
+}
+#define HIPCHK(c, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), SARX_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+
+extern "C" {
+
+int sarx_version(void) { return SARX_VERSION; }
+
+const char* sarx_last_error(const sarx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int sarx_device_count(int* out_count) {
+    if (!out_count) return fail(nullptr, SARX_ERR_INVALID, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *out_count = 0; return fail(nullptr, SARX_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *out_count = n;
+    return SARX_OK;
+}
+
+int sarx_init(int device_id, sarx_ctx** out_ctx) {
+    if (!out_ctx) return fail(nullptr, SARX_ERR_INVALID, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, SARX_ERR_DEVICE, "no HIP device available (%s); libsarx has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, SARX_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+    HIPCHK(nullptr, hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(nullptr, hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, SARX_ERR_UNSUPPORTED, "device %d is %s; libsarx is built for gfx950 only", device_id, prop.gcnArchName);
+    sarx_ctx* c = new sarx_ctx();
+    c->device = device_id;
+    HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(nullptr, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (int i = 0; i < N_EVENTS; ++i) HIPCHK(nullptr, hipEventCreate(&c->ev[i]));
+    HIPCHK(nullptr, hipEventCreateWithFlags(&c->comm_fence, hipEventDisableTiming));
+    // twiddle tables for every power of two up to TW_MAX, fp64-evaluated
+    std::vector<float2> tw(2 * TW_MAX);
+    tw[0] = tw[1] = make_float2(1.f, 0.f);
+    for (int n2 = 2; n2 <= TW_MAX; n2 <<= 1)
+        for (int m = 0; m < n2; ++m) {
+            const double ang = -2.0 * M_PI * (double)m / (double)n2;
+            tw[n2 + m] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+    HIPCHK(nullptr, hipMalloc(&c->tw_all, tw.size() * sizeof(float2)));
+    HIPCHK(nullptr, hipMemcpy(c->tw_all, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(nullptr, hipMalloc(&c->ati_part_max, 4096 * sizeof(float)));
+    HIPCHK(nullptr, hipMalloc(&c->ati_part_sum, 4096 * sizeof(double2)));
+    HIPCHK(nullptr, hipMalloc(&c->ati_out3, 3 * sizeof(double)));
+    *out_ctx = c;
+    return SARX_OK;
+}
+
+int sarx_destroy(sarx_ctx* c) {
+    if (!c) return SARX_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    hipFree(c->tw_all); hipFree(c->ati_part_max); hipFree(c->ati_part_sum); hipFree(c->ati_out3);
+    for (int i = 0; i < N_EVENTS; ++i) hipEventDestroy(c->ev[i]);
+    hipEventDestroy(c->comm_fence);
+    hipStreamDestroy(c->stream);
+    hipStreamDestroy(c->comm_stream);
+    delete c;
+    return SARX_OK;
+}
+
+int sarx_device_info(sarx_ctx* c, char* name, size_t name_len, int* cus, uint64_t* hbm, char* arch, size_t arch_len) {
+    if (!c) return fail(nullptr, SARX_ERR_INVALID, "ctx is NULL");
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    if (name && name_len) snprintf(name, name_len, "%s", prop.name);
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm) *hbm = (uint64_t)prop.totalGlobalMem;
+    return SARX_OK;
+}
+
+// ---- memory / timing ----------------------------------------------------------
+#define NEED_CTX(c) do { if (!(c)) return fail(nullptr, SARX_ERR_INVALID, "ctx is NULL"); hipSetDevice((c)->device); } while (0)
+
+int sarx_malloc(sarx_ctx* c, size_t bytes, void** out) {
+    NEED_CTX(c);
+    if (!out) return fail(c, SARX_ERR_INVALID, "out_dptr is NULL");
+    *out = nullptr;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return SARX_OK;
+}
+int sarx_free(sarx_ctx* c, void* p) { NEED_CTX(c); HIPCHK(c, hipFree(p)); return SARX_OK; }
+int sarx_memcpy_h2d(sarx_ctx* c, void* d, const void* s, size_t n) {
+    NEED_CTX(c);
+    HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SARX_OK;
+}
+int sarx_memcpy_d2h(sarx_ctx* c, void* d, const void* s, size_t n) {
+    NEED_CTX(c);
+    HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SARX_OK;
+}
+int sarx_memcpy_d2d(sarx_ctx* c, void* d, const void* s, size_t n) {
+    NEED_CTX(c);
+    HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream));
+    return SARX_OK;
+}
+int sarx_memset(sarx_ctx* c, void* d, int v, size_t n) { NEED_CTX(c); HIPCHK(c, hipMemsetAsync(d, v, n, c->stream)); return SARX_OK; }
+int sarx_sync(sarx_ctx* c) {
+    NEED_CTX(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    return SARX_OK;
+}
+int sarx_event_record(sarx_ctx* c, int slot) {
+    NEED_CTX(c);
+    if (slot < 0 || slot >= N_EVENTS) return fail(c, SARX_ERR_INVALID, "event slot %d out of range", slot);
+    HIPCHK(c, hipEventRecord(c->ev[slot], c->stream));
+    c->ev_set[slot] = true;
+    return SARX_OK;
+}
+int sarx_event_elapsed_ms(sarx_ctx* c, int a, int b, float* ms) {
+    NEED_CTX(c);
+    if (a < 0 || a >= N_EVENTS || b < 0 || b >= N_EVENTS || !ms) return fail(c, SARX_ERR_INVALID, "bad event slots");
+    if (!c->ev_set[a] || !c->ev_set[b]) return fail(c, SARX_ERR_INVALID, "event slot not recorded");
+    HIPCHK(c, hipEventSynchronize(c->ev[b]));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
+    return SARX_OK;
+}
+
+// ---- CSA plan -----------------------------------------------------------------
+int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_params* prm, unsigned flags, sarx_plan** out) {
+    NEED_CTX(c);
+    if (!out || !prm) return fail(c, SARX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (!is_pow2(n_az) || !is_pow2(n_rg) || n_az < 16 || n_rg < 16 || n_az > TW_MAX || n_rg > TW_MAX)
+        return fail(c, SARX_ERR_UNSUPPORTED, "n_az=%d n_rg=%d: sizes must be powers of two in [16, %d]", n_az, n_rg, TW_MAX);
+    if (flags & ~(SARX_OUT_RG_MAJOR | SARX_FUSE_RANGE)) return fail(c, SARX_ERR_INVALID, "unknown plan flags 0x%x", flags);
+    if (!(prm->sample_rate_hz > 0) || !(prm->prf_hz > 0) || !(prm->platform_speed_mps > 0) ||
+        !(prm->wavelength_m > 0) || prm->chirp_rate_hz_s == 0.0)
+        return fail(c, SARX_ERR_INVALID, "radar parameters must be positive (chirp rate non-zero)");
+    sarx_plan* p = new sarx_plan();
+    p->ctx = c; p->n_az = n_az; p->n_rg = n_rg; p->flags = flags; p->p = *prm;
+    p->az_s = (n_az <= 128) ? n_az : (1 << (ilog2(n_az) / 2));
+    p->az_w = (n_rg % 32 == 0) ? 32 : 16;
+
+    // migration factors, natural fftfreq order (sar_ati_dcpa_sim_csa.py:225,244-249,262)
+    const double lam = prm->wavelength_m, Kr = prm->chirp_rate_hz_s, Vr = prm->platform_speed_mps, Rref = prm->range_ref_m;
+    const double fa_step = 1.0 / ((double)n_az * (1.0 / prm->prf_hz));
+    std::vector<double2> c1(n_az), c2(n_az), c3(n_az);
+    for (int i = 0; i < n_az; ++i) {
+        const int ks = (i < n_az / 2) ? i : i - n_az;
+        const double fa = (double)ks * fa_step;
+        const double u = lam * fa / (2.0 * Vr);
+        double arg = 1.0 - u * u;
+        if (arg < 0) arg = 1e-9;                           // :246 sets, does not clamp to 0
+        const double D = sqrt(arg);
+        const double Cs = 1.0 / D - 1.0;
+        const double tau_ref = 2.0 * Rref / (C_LIGHT * D);
+        c1[i] = make_double2(-0.5 * Kr * Cs, tau_ref);
+        c2[i] = make_double2(0.5 / (Kr * (1.0 + Cs)), 2.0 * Rref * Cs / C_LIGHT);
+        c3[i] = make_double2(C_LIGHT * D / lam, -0.5 * Kr * Cs * (1.0 + Cs));
+    }
+    const size_t tb = (size_t)n_az * sizeof(double2), img = (size_t)n_az * n_rg * sizeof(float2);
+    auto bail = [&](hipError_t e, const char* what) {
+        int rc = fail(c, e == hipErrorOutOfMemory ? SARX_ERR_NOMEM : SARX_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+        sarx_csa_plan_destroy(p);
+        return rc;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&p->c1, tb)) != hipSuccess) return bail(e, "hipMalloc c1");
+    if ((e = hipMalloc(&p->c2, tb)) != hipSuccess) return bail(e, "hipMalloc c2");
+    if ((e = hipMalloc(&p->c3, tb)) != hipSuccess) return bail(e, "hipMalloc c3");
+    if ((e = hipMemcpy(p->c1, c1.data(), tb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload c1");
+    if ((e = hipMemcpy(p->c2, c2.data(), tb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload c2");
+    if ((e = hipMemcpy(p->c3, c3.data(), tb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload c3");
+    if ((e = hipMalloc(&p->buf_b, img)) != hipSuccess) return bail(e, "hipMalloc scratch image");
+    p->bytes = 3 * tb + img;
+    if (flags & SARX_OUT_RG_MAJOR) {
+        if ((e = hipMalloc(&p->buf_a, img)) != hipSuccess) return bail(e, "hipMalloc second scratch image");
+        p->bytes += img;
+    }
+    *out = p;
+    return SARX_OK;
+}
+
+int sarx_csa_plan_destroy(sarx_plan* p) {
+    if (!p) return SARX_OK;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    hipFree(p->c1); hipFree(p->c2); hipFree(p->c3);
+    hipFree(p->buf_a); hipFree(p->buf_b); hipFree(p->h_in); hipFree(p->h_out);
+    delete p;
+    return SARX_OK;
+}
+
+int sarx_csa_plan_bytes(const sarx_plan* p, uint64_t* out) {
+    if (!p || !out) return fail(p ? p->ctx : nullptr, SARX_ERR_INVALID, "NULL argument");
+    *out = p->bytes;
+    return SARX_OK;
+}
+
+int sarx_csa_axes(const sarx_plan* p, double* range_axis, double* cross_range_axis) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    const double dt = 1.0 / p->p.sample_rate_hz;
+    if (range_axis)
+        for (int j = 0; j < p->n_rg; ++j) range_axis[j] = C_LIGHT * (p->p.t_start_fast_s + (double)j * dt) / 2.0;   // :219,346
+    if (cross_range_axis) {
+        // t_slow = arange/prf; t_slow -= mean; * Vr   (:392-394), pairwise mean like NumPy is not
+        // needed: the reference result is reproduced to 1e-13 relative, stated in the test
+        double mean = 0.0;
+        for (int i = 0; i < p->n_az; ++i) mean += (double)i / p->p.prf_hz;
+        mean /= (double)p->n_az;
+        for (int i = 0; i < p->n_az; ++i) cross_range_axis[i] = ((double)i / p->p.prf_hz - mean) * p->p.platform_speed_mps;
+    }
+    return SARX_OK;
+}
+
+static RangeArgs range_args(const sarx_plan* p, const void* in, void* out) {
+    RangeArgs a{};
+    a.in = (const float2*)in; a.out = (float2*)out;
+    a.tw = p->ctx->tw_all + p->n_rg;
+    a.c2 = p->c2; a.c3 = p->c3;
+    a.dt = 1.0 / p->p.sample_rate_hz;
+    a.df = 1.0 / ((double)p->n_rg * a.dt);           // numpy.fft.fftfreq step
+    a.t_start = p->p.t_start_fast_s;
+    a.t0 = 2.0 * p->p.range_ref_m / C_LIGHT;
+    a.inv_n = 1.0f / (float)p->n_rg;
+    a.n_az = p->n_az;
+    return a;
+}
+
+// azimuth FFT (+epilogue) in -> out via tmp (tmp unused for single-step sizes); in is not modified
+static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out) {
+    sarx_ctx* c = p->ctx;
+    const int n = p->n_az, S = p->az_s, RA = n / S;
+    AzArgs a{};
+    a.tw_n = c->tw_all + n;
+    a.c1 = p->c1;
+    a.dt = 1.0 / p->p.sample_rate_hz;
+    a.t_start = p->p.t_start_fast_s;
+    a.scale = 1.0f / (float)n;
+    a.n_rg = p->n_rg;
+    const int epi_last = inv ? AZ_EPI_SCALE : AZ_EPI_PHI1;
+    if (S == n) {          // one tile spans the whole azimuth extent
+        a.in = (const float2*)in; a.out = (float2*)out;
+        a.tw_r = c->tw_all + n;
+        a.in_q_stride = 0; a.in_m_stride = 1; a.out_q_stride = 0; a.out_m_stride = 1;
+        HIPCHK(c, launch_az_tile(n, p->az_w, inv, epi_last, a, 1, c->stream));
+        return SARX_OK;
+    }
+    // step A: rows q + m*S, FFT over m (length RA), twiddle W_n^(q*m'), same rows out
+    a.in = (const float2*)in; a.out = (float2*)tmp;
+    a.tw_r = c->tw_all + RA;
+    a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
+    HIPCHK(c, launch_az_tile(RA, p->az_w, inv, AZ_EPI_TWIDDLE, a, S, c->stream));
+    // step B: rows q*S + m, FFT over m (length S), out rows q + m'*RA (natural bin order)
+    a.in = (const float2*)tmp; a.out = (float2*)out;
+    a.tw_r = c->tw_all + S;
+    a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
+    HIPCHK(c, launch_az_tile(S, p->az_w, inv, epi_last, a, RA, c->stream));
+    return SARX_OK;
+}
+
+int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!d_in || !d_out) return fail(c, SARX_ERR_INVALID, "NULL image pointer");
+    switch (pass_id) {
+        case SARX_PASS_AZ_FFT_PHI1:
+        case SARX_PASS_AZ_IFFT:
+            if (d_in == d_out || d_in == p->buf_b || d_out == p->buf_b)
+                return fail(c, SARX_ERR_INVALID, "azimuth passes are out-of-place");
+            return az_pass(p, pass_id == SARX_PASS_AZ_IFFT, d_in, p->buf_b, d_out);
+        case SARX_PASS_RG_FFT_PHI2: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_FFT_PHI2, a, c->stream)); return SARX_OK; }
+        case SARX_PASS_RG_IFFT_PHI3: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_IFFT_PHI3, a, c->stream)); return SARX_OK; }
+        case SARX_PASS_RG_FUSED_23: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_FUSED, a, c->stream)); return SARX_OK; }
+        case 100: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_FFT, a, c->stream)); return SARX_OK; }   // plain FFT (tests)
+        case 101: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_IFFT, a, c->stream)); return SARX_OK; }  // plain IFFT (tests)
+    }
+    return fail(c, SARX_ERR_INVALID, "unknown pass id %d", pass_id);
+}
+
+int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!d_phist || !d_image || d_phist == d_image) return fail(c, SARX_ERR_INVALID, "image pointers NULL or aliased");
+    const bool rg_major = p->flags & SARX_OUT_RG_MAJOR;
+    int rc;
+    // pass 1: azimuth FFT + Phi_1: phist -> (image as step-A scratch) -> buf_b
+    if ((rc = az_pass(p, false, d_phist, d_image, p->buf_b)) != SARX_OK) return rc;
+    // passes 2, 3 in place on buf_b
+    if (p->flags & SARX_FUSE_RANGE) {
+        RangeArgs a = range_args(p, p->buf_b, p->buf_b);
+        HIPCHK(c, launch_range_pass(p->n_rg, RG_FUSED, a, c->stream));
+    } else {
+        RangeArgs a = range_args(p, p->buf_b, p->buf_b);
+        HIPCHK(c, launch_range_pass(p->n_rg, RG_FFT_PHI2, a, c->stream));
+        HIPCHK(c, launch_range_pass(p->n_rg, RG_IFFT_PHI3, a, c->stream));
+    }
+    // pass 4: azimuth IFFT; step A in place on buf_b, step B out to the image (or buf_a before the corner turn)
+    float2* last = rg_major ? p->buf_a : (float2*)d_image;
+    if (p->az_s == p->n_az) {
+        if ((rc = az_pass(p, true, p->buf_b, nullptr, last)) != SARX_OK) return rc;
+    } else {
+        if ((rc = az_pass(p, true, p->buf_b, p->buf_b, last)) != SARX_OK) return rc;
+    }
+    if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
+    return SARX_OK;
+}
+
+int sarx_csa_focus_host(sarx_plan* p, const void* phist_host, void* image_host) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!phist_host || !image_host) return fail(c, SARX_ERR_INVALID, "NULL host pointer");
+    const size_t img = (size_t)p->n_az * p->n_rg * sizeof(float2);
+    if (!p->h_in) { hipError_t e = hipMalloc(&p->h_in, img); if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc staging: %s", hipGetErrorString(e)); }
+    if (!p->h_out) { hipError_t e = hipMalloc(&p->h_out, img); if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc staging: %s", hipGetErrorString(e)); }
+    HIPCHK(c, hipMemcpyAsync(p->h_in, phist_host, img, hipMemcpyHostToDevice, c->stream));
+    int rc = sarx_csa_focus_dev(p, p->h_in, p->h_out);
+    if (rc != SARX_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(image_host, p->h_out, img, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SARX_OK;
+}
+
+// ---- ATI / DPCA ------------------------------------------------------------------
+int sarx_ati_dpca_dev(sarx_ctx* c, const void* s1, const void* s2, size_t n, double cal_phase,
+                      const sarx_ati_outputs* o, double* max_mag, double* sum2) {
+    NEED_CTX(c);
+    if (!s1 || !s2 || !o || !o->ati_phase || !o->slc1_mag || !o->dpca_mag) return fail(c, SARX_ERR_INVALID, "NULL required pointer");
+    if (n == 0) { if (max_mag) *max_mag = 0; if (sum2) sum2[0] = sum2[1] = 0; return SARX_OK; }
+    AtiArgs a{};
+    a.s1 = (const float2*)s1; a.s2 = (const float2*)s2; a.n = n;
+    a.cal_c = (float)cos(cal_phase); a.cal_s = (float)sin(cal_phase);
+    a.ati_phase = o->ati_phase; a.mag1 = o->slc1_mag; a.dpca_mag = o->dpca_mag;
+    a.interf = (float2*)o->ati_interf; a.diff = (float2*)o->dpca_diff;
+    a.mag2 = o->slc2_mag; a.ph1 = o->slc1_phase; a.ph2 = o->slc2_phase; a.dpca_phase = o->dpca_phase;
+    a.part_max = c->ati_part_max; a.part_sum = c->ati_part_sum;
+    HIPCHK(c, launch_ati_dpca(a, c->stream));
+    HIPCHK(c, launch_ati_finish(c->ati_part_max, c->ati_part_sum, ati_blocks(n), c->ati_out3, c->stream));
+    if (max_mag || sum2) {
+        double h[3];
+        HIPCHK(c, hipMemcpyAsync(h, c->ati_out3, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (max_mag) *max_mag = h[0];
+        if (sum2) { sum2[0] = h[1]; sum2[1] = h[2]; }
+    }
+    return SARX_OK;
+}
+
+int sarx_mask_phase_dev(sarx_ctx* c, const float* phase, const float* mag, size_t n, float thr, float* out) {
+    NEED_CTX(c);
+    if (!phase || !mag || !out) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (n == 0) return SARX_OK;
+    HIPCHK(c, launch_mask_phase(phase, mag, n, thr, out, c->stream));
+    return SARX_OK;
+}
+
+int sarx_corner_turn_dev(sarx_ctx* c, const void* in, void* out, int rows, int cols) {
+    NEED_CTX(c);
+    if (!in || !out || in == out || rows <= 0 || cols <= 0) return fail(c, SARX_ERR_INVALID, "bad corner-turn arguments");
+    HIPCHK(c, launch_corner_turn((const float2*)in, (float2*)out, rows, cols, c->stream));
+    return SARX_OK;
+}
+
+int sarx_multilook_dev(sarx_ctx* c, const void* in, float* out, int rows, int cols, int looks) {
+    NEED_CTX(c);
+    if (!in || !out) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (looks < 1 || looks > 512 || (looks & (looks - 1)) || rows % looks || cols % looks || (cols & 1))
+        return fail(c, SARX_ERR_UNSUPPORTED, "looks=%d must be a power of two <= 512 dividing rows=%d and cols=%d", looks, rows, cols);
+    HIPCHK(c, launch_multilook((const float2*)in, out, rows, cols, looks, c->stream));
+    return SARX_OK;
+}
+
+int sarx_fill_noise_c64(sarx_ctx* c, void* buf, size_t n, uint64_t seed) {
+    NEED_CTX(c);
+    if (!buf) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (n) HIPCHK(c, launch_fill_noise((float2*)buf, n, seed, c->stream));
+    return SARX_OK;
+}
+
+// ---- RCCL ------------------------------------------------------------------------
+int sarx_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(nullptr, SARX_ERR_INVALID, "id_out is NULL");
+    std::string err;
+    if (!load_rccl(err)) return fail(nullptr, SARX_ERR_COMM, "%s", err.c_str());
+    static_assert(sizeof(ncclUniqueId) == SARX_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, SARX_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    memcpy(id_out, &id, sizeof id);
+    return SARX_OK;
+}
+int sarx_comm_init(sarx_ctx* c, const void* id, int n_ranks, int rank) {
+    NEED_CTX(c);
+    if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, SARX_ERR_INVALID, "bad comm arguments");
+    std::string err;
+    if (!load_rccl(err)) return fail(c, SARX_ERR_COMM, "%s", err.c_str());
+    if (c->comm) return fail(c, SARX_ERR_COMM, "communicator already initialised");
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, uid, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; return fail(c, SARX_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+    c->n_ranks = n_ranks; c->rank = rank;
+    return SARX_OK;
+}
+int sarx_allgather_dev(sarx_ctx* c, const void* send, void* recv, size_t bytes_per_rank) {
+    NEED_CTX(c);
+    if (!c->comm) return fail(c, SARX_ERR_COMM, "communicator not initialised");
+    if (!send || !recv || (bytes_per_rank & 3)) return fail(c, SARX_ERR_INVALID, "bad all-gather arguments");
+    HIPCHK(c, hipEventRecord(c->comm_fence, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->comm_fence, 0));
+    ncclResult_t r = g_rccl.AllGather(send, recv, bytes_per_rank / 4, ncclFloat32, c->comm, c->comm_stream);
+    if (r != ncclSuccess) return fail(c, SARX_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return SARX_OK;
+}
+int sarx_comm_sync(sarx_ctx* c) { NEED_CTX(c); HIPCHK(c, hipStreamSynchronize(c->comm_stream)); return SARX_OK; }
+int sarx_comm_destroy(sarx_ctx* c) {
+    NEED_CTX(c);
+    if (c->comm) { hipStreamSynchronize(c->comm_stream); g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    return SARX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+"""sarx: MI355X-native backend for the CSA focus + ATI/DPCA path.
+
+Python host code with the reference's function signatures over a ctypes C ABI
+(include/sarx.h) to hand-written HIP kernels (csrc/).  No torch on this path.
+"""
+from ._ffi import SarxError
+from .engine import Context, CsaPlan, DeviceBuffer, default_context
+from .focus import (ati_dpca, clear_plan_cache, dpca_pulse_shift, focus_ati_dpca, phase_balance, sar_focus_csa)
+
+__all__ = ["SarxError", "Context", "CsaPlan", "DeviceBuffer", "default_context", "sar_focus_csa", "ati_dpca",
+           "dpca_pulse_shift", "phase_balance", "focus_ati_dpca", "clear_plan_cache"]

@@ -1,0 +1,104 @@
+"""ctypes binding of libsarx.so (include/sarx.h).  No torch, no cffi.
+
+The library is built in-tree by ``csrc/Makefile`` (``__graft_entry__.build()``).
+There is no CPU fallback: every compute entry point needs a gfx950 device and
+raises :class:`SarxError` otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsarx.so")
+
+COMM_ID_BYTES = 128
+OUT_AZ_MAJOR, OUT_RG_MAJOR, FUSE_RANGE = 0, 1, 2
+PASS_AZ_FFT_PHI1, PASS_RG_FFT_PHI2, PASS_RG_IFFT_PHI3, PASS_AZ_IFFT, PASS_RG_FUSED_23 = 1, 2, 3, 4, 23
+PASS_TEST_RG_FFT, PASS_TEST_RG_IFFT = 100, 101
+
+
+class SarxError(RuntimeError):
+    """Raised with sarx_last_error() text when a libsarx call fails."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libsarx error {code}: {msg}")
+        self.code = code
+
+
+class RadarParams(C.Structure):
+    """sarx_radar_params: positional args of sar_focus_csa after phist
+    (sar_ati_dcpa_sim_csa.py:202)."""
+    _fields_ = [(n, C.c_double) for n in (
+        "wavelength_m", "pulse_width_s", "chirp_rate_hz_s", "sample_rate_hz", "prf_hz",
+        "platform_speed_mps", "range_ref_m", "t_start_fast_s")]
+
+
+class AtiOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ati_phase", "slc1_mag", "dpca_mag", "ati_interf", "dpca_diff", "slc2_mag", "slc1_phase",
+        "slc2_phase", "dpca_phase")]
+
+
+# name -> (restype, argtypes): every symbol declared in include/sarx.h
+_vp, _i, _sz, _u64, _d, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.c_double, C.c_float
+_P = C.POINTER
+SIGNATURES = {
+    "sarx_version": (_i, []),
+    "sarx_init": (_i, [_i, _P(_vp)]),
+    "sarx_destroy": (_i, [_vp]),
+    "sarx_last_error": (C.c_char_p, [_vp]),
+    "sarx_device_count": (_i, [_P(_i)]),
+    "sarx_device_info": (_i, [_vp, C.c_char_p, _sz, _P(_i), _P(_u64), C.c_char_p, _sz]),
+    "sarx_malloc": (_i, [_vp, _sz, _P(_vp)]),
+    "sarx_free": (_i, [_vp, _vp]),
+    "sarx_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_memset": (_i, [_vp, _vp, _i, _sz]),
+    "sarx_sync": (_i, [_vp]),
+    "sarx_event_record": (_i, [_vp, _i]),
+    "sarx_event_elapsed_ms": (_i, [_vp, _i, _i, _P(_f)]),
+    "sarx_csa_plan_create": (_i, [_vp, _i, _i, _P(RadarParams), C.c_uint, _P(_vp)]),
+    "sarx_csa_plan_destroy": (_i, [_vp]),
+    "sarx_csa_axes": (_i, [_vp, _vp, _vp]),
+    "sarx_csa_focus_host": (_i, [_vp, _vp, _vp]),
+    "sarx_csa_focus_dev": (_i, [_vp, _vp, _vp]),
+    "sarx_csa_pass": (_i, [_vp, _i, _vp, _vp]),
+    "sarx_csa_plan_bytes": (_i, [_vp, _P(_u64)]),
+    "sarx_ati_dpca_dev": (_i, [_vp, _vp, _vp, _sz, _d, _P(AtiOutputs), _P(_d), _P(_d)]),
+    "sarx_mask_phase_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
+    "sarx_corner_turn_dev": (_i, [_vp, _vp, _vp, _i, _i]),
+    "sarx_multilook_dev": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "sarx_fill_noise_c64": (_i, [_vp, _vp, _sz, _u64]),
+    "sarx_comm_unique_id": (_i, [_vp]),
+    "sarx_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "sarx_allgather_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_comm_sync": (_i, [_vp]),
+    "sarx_comm_destroy": (_i, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsarx.so once and attach prototypes.  Fails loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SarxError(-3, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C nis-sar-amtigmti-video_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = load().sarx_last_error(ctx)
+        raise SarxError(rc, msg.decode() if msg else "unknown")

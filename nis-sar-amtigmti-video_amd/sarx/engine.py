@@ -1,0 +1,218 @@
+"""Thin object layer over the C ABI: Context (one per GPU), DeviceBuffer, CsaPlan."""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import SarxError, check
+
+
+class DeviceBuffer:
+    """HBM allocation owned by a Context (freed with it or on release())."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(ctx.lib.sarx_malloc(ctx.h, self.nbytes, C.byref(p)), ctx.h)
+        self.ptr = p.value
+        ctx._live[id(self)] = self.ptr
+
+    def release(self):
+        if self.ptr is not None and self.ctx.h is not None:
+            self.ctx.lib.sarx_free(self.ctx.h, self.ptr)
+            self.ctx._live.pop(id(self), None)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > self.nbytes:
+            raise ValueError("upload larger than buffer")
+        check(self.ctx.lib.sarx_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes), self.ctx.h)
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("download larger than buffer")
+        check(self.ctx.lib.sarx_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes), self.ctx.h)
+        return out
+
+
+class Context:
+    """sarx_ctx wrapper: one per GPU, owns a compute stream and a comm stream."""
+
+    def __init__(self, device_id=0):
+        self.lib = _ffi.load()
+        h = C.c_void_p()
+        check(self.lib.sarx_init(int(device_id), C.byref(h)), None)
+        self.h = h.value
+        self.device_id = int(device_id)
+        self._live = {}
+        self._plans = weakref.WeakSet()
+
+    def close(self):
+        if self.h is not None:
+            for p in list(self._plans):
+                p.close()
+            for ptr in list(self._live.values()):
+                self.lib.sarx_free(self.h, ptr)
+            self._live.clear()
+            self.lib.sarx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory / sync / timing --
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return self.alloc(arr.nbytes).upload(arr)
+
+    def sync(self):
+        check(self.lib.sarx_sync(self.h), self.h)
+
+    def record(self, slot):
+        check(self.lib.sarx_event_record(self.h, slot), self.h)
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        check(self.lib.sarx_event_elapsed_ms(self.h, a, b, C.byref(ms)), self.h)
+        return ms.value
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        arch = C.create_string_buffer(64)
+        cus = C.c_int()
+        hbm = C.c_uint64()
+        check(self.lib.sarx_device_info(self.h, name, 256, C.byref(cus), C.byref(hbm), arch, 64), self.h)
+        return {"name": name.value.decode(), "arch": arch.value.decode(), "compute_units": cus.value,
+                "hbm_bytes": hbm.value}
+
+    # -- kernels that are not tied to a plan --
+    def fill_noise(self, buf, n, seed):
+        check(self.lib.sarx_fill_noise_c64(self.h, buf.ptr, int(n), int(seed)), self.h)
+
+    def corner_turn(self, src, dst, rows, cols):
+        check(self.lib.sarx_corner_turn_dev(self.h, src.ptr, dst.ptr, int(rows), int(cols)), self.h)
+
+    def multilook(self, src, dst, rows, cols, looks):
+        check(self.lib.sarx_multilook_dev(self.h, src.ptr, dst.ptr, int(rows), int(cols), int(looks)), self.h)
+
+    def mask_phase(self, phase, mag, n, thr, out):
+        check(self.lib.sarx_mask_phase_dev(self.h, phase.ptr, mag.ptr, int(n), float(thr), out.ptr), self.h)
+
+    def ati_dpca(self, slc1, slc2, n, cal_phase, outs, want_stats=True):
+        """outs: dict name -> DeviceBuffer for fields of sarx_ati_outputs."""
+        o = _ffi.AtiOutputs()
+        for k, _ in _ffi.AtiOutputs._fields_:
+            b = outs.get(k)
+            setattr(o, k, b.ptr if b is not None else None)
+        mx = C.c_double()
+        sm = (C.c_double * 2)()
+        check(self.lib.sarx_ati_dpca_dev(self.h, slc1.ptr, slc2.ptr, int(n), float(cal_phase), C.byref(o),
+                                         C.byref(mx) if want_stats else None, sm if want_stats else None), self.h)
+        return (mx.value, complex(sm[0], sm[1])) if want_stats else None
+
+    # -- RCCL --
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(_ffi.COMM_ID_BYTES)
+        check(_ffi.load().sarx_comm_unique_id(buf), None)
+        return buf.raw
+
+    def comm_init(self, uid, n_ranks, rank):
+        check(self.lib.sarx_comm_init(self.h, uid, int(n_ranks), int(rank)), self.h)
+
+    def allgather(self, send, recv, bytes_per_rank):
+        check(self.lib.sarx_allgather_dev(self.h, send.ptr, recv.ptr, int(bytes_per_rank)), self.h)
+
+    def comm_sync(self):
+        check(self.lib.sarx_comm_sync(self.h), self.h)
+
+
+class CsaPlan:
+    """sarx_plan wrapper for one (n_az, n_rg, radar) geometry."""
+
+    def __init__(self, ctx, n_az, n_rg, wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz,
+                 prf_hz, platform_speed_mps, range_ref_m, t_start_fast, flags=_ffi.OUT_AZ_MAJOR):
+        self.ctx = ctx
+        self.n_az, self.n_rg, self.flags = int(n_az), int(n_rg), int(flags)
+        self.params = _ffi.RadarParams(wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+                                       platform_speed_mps, range_ref_m, t_start_fast)
+        h = C.c_void_p()
+        check(ctx.lib.sarx_csa_plan_create(ctx.h, self.n_az, self.n_rg, C.byref(self.params), self.flags,
+                                           C.byref(h)), ctx.h)
+        self.h = h.value
+        ctx._plans.add(self)
+
+    def close(self):
+        if self.h is not None and self.ctx.h is not None:
+            self.ctx.lib.sarx_csa_plan_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def rg_major(self):
+        return bool(self.flags & _ffi.OUT_RG_MAJOR)
+
+    def axes(self):
+        ra = np.empty(self.n_rg, dtype=np.float64)
+        ca = np.empty(self.n_az, dtype=np.float64)
+        check(self.ctx.lib.sarx_csa_axes(self.h, ra.ctypes.data, ca.ctypes.data), self.ctx.h)
+        return ra, ca
+
+    def scratch_bytes(self):
+        b = C.c_uint64()
+        check(self.ctx.lib.sarx_csa_plan_bytes(self.h, C.byref(b)), self.ctx.h)
+        return b.value
+
+    def focus_host(self, phist_c64):
+        """[n_az x n_rg] complex64 host array -> focused image in the plan's layout (host)."""
+        a = np.ascontiguousarray(phist_c64, dtype=np.complex64)
+        if a.shape != (self.n_az, self.n_rg):
+            raise ValueError(f"phist shape {a.shape} != plan ({self.n_az}, {self.n_rg})")
+        shape = (self.n_rg, self.n_az) if self.rg_major else (self.n_az, self.n_rg)
+        out = np.empty(shape, dtype=np.complex64)
+        check(self.ctx.lib.sarx_csa_focus_host(self.h, a.ctypes.data, out.ctypes.data), self.ctx.h)
+        return out
+
+    def focus_dev(self, d_phist, d_image):
+        check(self.ctx.lib.sarx_csa_focus_dev(self.h, d_phist.ptr, d_image.ptr), self.ctx.h)
+
+    def run_pass(self, pass_id, d_in, d_out):
+        check(self.ctx.lib.sarx_csa_pass(self.h, int(pass_id), d_in.ptr, d_out.ptr), self.ctx.h)
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=0):
+    """Process-wide Context per device (created on first use)."""
+    c = _default_ctx.get(device_id)
+    if c is None or c.h is None:
+        c = _default_ctx[device_id] = Context(device_id)
+    return c
+
+
+__all__ = ["Context", "CsaPlan", "DeviceBuffer", "SarxError", "default_context"]

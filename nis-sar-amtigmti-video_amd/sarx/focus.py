@@ -1,0 +1,168 @@
+"""Host-side mirror of the reference's functions for the CSA / ATI-DPCA path.
+
+Same names, argument order and return tuples as the reference scripts, so a
+caller switches by changing an import.  All arithmetic happens in libsarx's
+HIP kernels; this module only validates, stages buffers and shapes results.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _ffi
+from .engine import CsaPlan, default_context
+
+_plan_cache = {}
+_PLAN_CACHE_MAX = 4
+
+
+def _get_plan(ctx, n_az, n_rg, args, flags):
+    key = (ctx.device_id, id(ctx), n_az, n_rg, tuple(float(a) for a in args), flags)
+    plan = _plan_cache.get(key)
+    if plan is None or plan.h is None:
+        while len(_plan_cache) >= _PLAN_CACHE_MAX:       # plans hold full-image scratch
+            _plan_cache.pop(next(iter(_plan_cache))).close()
+        plan = _plan_cache[key] = CsaPlan(ctx, n_az, n_rg, *args, flags=flags)
+    return plan
+
+
+def clear_plan_cache():
+    for p in _plan_cache.values():
+        p.close()
+    _plan_cache.clear()
+
+
+def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+                  platform_speed_mps, range_ref_m, t_start_fast, *, ctx=None, fuse_range=True,
+                  materialize_transpose=False):
+    """Chirp Scaling focus on the GPU; drop-in for the reference function of the
+    same name (sar_ati_dcpa_sim_csa.py:202-396).
+
+    phist : [N_pulses x N_samples] complex (any complex/float dtype; computed as complex64)
+    returns (img.T [N_rg x N_az] complex64, range_axis [N_rg], cross_range_axis [N_az])
+
+    Like the reference, the image comes back as the transpose *view* of an
+    [N_az x N_rg] row-major array (:396 returns ``img.T``);
+    ``materialize_transpose=True`` corner-turns on the GPU instead and returns a
+    C-contiguous [N_rg x N_az] array.  ``pulse_width_sec`` is accepted and
+    unused, exactly as in the reference.
+    """
+    a = np.asarray(phist)
+    if a.ndim != 2:
+        raise ValueError("phist must be 2-D [N_pulses x N_samples]")
+    n_az, n_rg = a.shape
+    ctx = ctx or default_context()
+    flags = (_ffi.FUSE_RANGE if fuse_range else 0) | (_ffi.OUT_RG_MAJOR if materialize_transpose else 0)
+    args = (center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+            platform_speed_mps, range_ref_m, t_start_fast)
+    plan = _get_plan(ctx, n_az, n_rg, args, flags)
+    img = plan.focus_host(a.astype(np.complex64, copy=False))
+    range_axis, cross_range_axis = plan.axes()
+    return (img if materialize_transpose else img.T), range_axis, cross_range_axis
+
+
+def dpca_pulse_shift(raw_rx1, raw_rx2):
+    """DPCA co-registration by one pulse (sar_ati_dcpa_sim_csa.py:402-403)."""
+    return raw_rx1[1:, :], raw_rx2[:-1, :]
+
+
+def _as_device_layout(x):
+    """complex64 array whose memory can be handed over without a transpose copy.
+    Returns (contiguous array, was_transposed)."""
+    x = np.asarray(x)
+    if x.ndim == 2 and x.flags.f_contiguous and not x.flags.c_contiguous:
+        return np.ascontiguousarray(x.T, dtype=np.complex64), True
+    return np.ascontiguousarray(x, dtype=np.complex64), False
+
+
+def ati_dpca(slc1, slc2, mask_frac=0.05, cal_phase=0.0, *, ctx=None, complex_products=False,
+             viewer_products=False):
+    """ATI interferogram + DPCA difference in one GPU kernel.
+
+    The reference has no function for this: the expressions are inline at
+    sar_ati_dcpa_sim_csa.py:414-419 (products), :447-449 (mask) and restated in
+    the viewer (sar_ati_dcpa_viewer_csa.py:42-52, which first applies
+    ``slc2 * exp(1j*cal_phase)``).  Returns a dict with the reference's
+    variable names: ati_phase, slc1_mag, dpca_mag, ati_phase_masked, mask,
+    max_mag, sum_interf (= sum(slc1*conj(slc2)), the phase-balance input);
+    optionally ati_interf / dpca_diff and the viewer's product names.
+    """
+    a, ta = _as_device_layout(slc1)
+    b, tb = _as_device_layout(slc2)
+    if a.shape != b.shape or ta != tb:
+        raise ValueError("slc1 and slc2 must have the same shape and memory order")
+    ctx = ctx or default_context()
+    n = a.size
+    d1, d2 = ctx.to_device(a), ctx.to_device(b)
+    names = ["ati_phase", "slc1_mag", "dpca_mag"]
+    if complex_products:
+        names += ["ati_interf", "dpca_diff"]
+    if viewer_products:
+        names += ["slc2_mag", "slc1_phase", "slc2_phase", "dpca_phase"]
+    outs = {k: ctx.alloc(n * (8 if k in ("ati_interf", "dpca_diff") else 4)) for k in names}
+    max_mag, sum_interf = ctx.ati_dpca(d1, d2, n, cal_phase, outs)
+    thr = np.float32(max_mag) * np.float32(mask_frac)
+    d_masked = ctx.alloc(n * 4)
+    ctx.mask_phase(outs["ati_phase"], outs["slc1_mag"], n, thr, d_masked)
+
+    def get(buf, dt):
+        arr = buf.download(dt, a.shape)
+        return arr.T if ta else arr
+
+    res = {k: get(v, np.complex64 if k in ("ati_interf", "dpca_diff") else np.float32) for k, v in outs.items()}
+    res["ati_phase_masked"] = get(d_masked, np.float32)
+    res["mask"] = res["slc1_mag"] > thr
+    res["max_mag"] = max_mag
+    res["sum_interf"] = sum_interf
+    if viewer_products:     # viewer's dictionary keys (sar_ati_dcpa_viewer_csa.py:44-52)
+        res.update({"Ch1 Magnitude": res["slc1_mag"], "Ch1 Phase": res["slc1_phase"],
+                    "Ch2 Magnitude": res["slc2_mag"], "Ch2 Phase": res["slc2_phase"],
+                    "DPCA Magnitude": res["dpca_mag"], "DPCA Phase": res["dpca_phase"],
+                    "ATI Phase": res["ati_phase"]})
+    for bufs in (d1, d2, d_masked, *outs.values()):
+        bufs.release()
+    return res
+
+
+def phase_balance(slc1, slc2, *, ctx=None):
+    """cal_phase = angle(mean(slc1*conj(slc2)))  (sar_ati_dcpa_viewer_csa.py:249-250),
+    from the fp64 reduction fused into the ATI kernel."""
+    r = ati_dpca(slc1, slc2, ctx=ctx)
+    return float(np.angle(r["sum_interf"]))
+
+
+def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz,
+                   prf_hz, platform_speed_mps, range_ref_m, t_start_fast, mask_frac=0.05, cal_phase=0.0, *,
+                   ctx=None, pulse_shift=True):
+    """The reference script's processing section in one call
+    (sar_ati_dcpa_sim_csa.py:402-419,447-449): pulse shift, CSA focus of both
+    channels, ATI/DPCA products.  Images stay on the GPU between the steps."""
+    ctx = ctx or default_context()
+    r1, r2 = (dpca_pulse_shift(raw_rx1, raw_rx2) if pulse_shift else (raw_rx1, raw_rx2))
+    r1 = np.ascontiguousarray(r1, dtype=np.complex64)
+    r2 = np.ascontiguousarray(r2, dtype=np.complex64)
+    n_az, n_rg = r1.shape
+    args = (center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+            platform_speed_mps, range_ref_m, t_start_fast)
+    plan = _get_plan(ctx, n_az, n_rg, args, _ffi.FUSE_RANGE)
+    n = n_az * n_rg
+    d_raw = ctx.alloc(n * 8)
+    d_s1, d_s2 = ctx.alloc(n * 8), ctx.alloc(n * 8)
+    d_raw.upload(r1)
+    plan.focus_dev(d_raw, d_s1)
+    ctx.sync()
+    d_raw.upload(r2)
+    plan.focus_dev(d_raw, d_s2)
+    outs = {k: ctx.alloc(n * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
+    max_mag, sum_interf = ctx.ati_dpca(d_s1, d_s2, n, cal_phase, outs)
+    thr = np.float32(max_mag) * np.float32(mask_frac)
+    d_masked = ctx.alloc(n * 4)
+    ctx.mask_phase(outs["ati_phase"], outs["slc1_mag"], n, thr, d_masked)
+    ra, ca = plan.axes()
+    res = {"slc1": d_s1.download(np.complex64, (n_az, n_rg)).T, "slc2": d_s2.download(np.complex64, (n_az, n_rg)).T,
+           "range_axis": ra, "cross_range": ca, "max_mag": max_mag, "sum_interf": sum_interf}
+    for k, v in outs.items():
+        res[k] = v.download(np.float32, (n_az, n_rg)).T
+    res["ati_phase_masked"] = d_masked.download(np.float32, (n_az, n_rg)).T
+    for b in (d_raw, d_s1, d_s2, d_masked, *outs.values()):
+        b.release()
+    return res

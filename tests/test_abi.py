@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: libsarx.so loads, exports every
+symbol include/sarx.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    with open(os.path.join(ROOT, "include", "sarx.h")) as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sarx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from sarx import _ffi
+    syms = _header_symbols()
+    assert len(syms) >= 30
+    assert set(syms) == set(_ffi.SIGNATURES), set(syms) ^ set(_ffi.SIGNATURES)
+
+
+def test_library_exports_every_symbol():
+    from sarx import _ffi
+    lib = _ffi.load()
+    for s in _header_symbols():
+        assert hasattr(lib, s), s
+    assert lib.sarx_version() == 100
+
+
+def test_struct_layouts():
+    from sarx import _ffi
+    assert C.sizeof(_ffi.RadarParams) == 8 * 8
+    assert C.sizeof(_ffi.AtiOutputs) == 9 * C.sizeof(C.c_void_p)
+
+
+def _have_gpu():
+    from sarx import _ffi
+    n = C.c_int()
+    return _ffi.load().sarx_device_count(C.byref(n)) == 0 and n.value > 0
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path raises; it never routes to the oracle."""
+    if _have_gpu():
+        pytest.skip("GPU present")
+    import sarx
+    with pytest.raises(sarx.SarxError) as e:
+        sarx.sar_focus_csa(np.zeros((64, 64), np.complex64), 0.03, 1e-6, 1e12, 6e8, 6e3, 7e3, 5e5, 3e-3)
+    assert "no HIP device" in str(e.value) or "HIP" in str(e.value)
+    with pytest.raises(sarx.SarxError):
+        sarx.ati_dpca(np.zeros((4, 4), np.complex64), np.zeros((4, 4), np.complex64))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "nis-sar-amtigmti-video_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                with open(os.path.join(dirpath, f)) as fh:
+                    src = fh.read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
