@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py - focused SAR frames/sec + HBM GB/s of the range FFT+phase pass.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384]
+
+One step = one CSA focus (azimuth FFT+Phi1, range FFT+Phi2+IFFT+Phi3, azimuth
+IFFT) of one 16384x16384 complex64 frame whose echo is already resident in HBM
+(synthetic complex Gaussian noise generated on the device).  For N > 1 the
+driver starts one process per GPU (torch.distributed.run); frames shard
+one-per-rank per step (weak scaling) and each step's frame is multilooked
+16x16 into its VideoSAR stack slot and all-gathered with RCCL on a second
+stream.  torch is used only for the gloo rendezvous/barrier; the GPU path is
+libsarx through ctypes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "nis-sar-amtigmti-video_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+LOOKS = 16
+
+
+def cpu_baseline(size):
+    """Oracle ("port") timed on this box's host cores, single thread, on a bounded sample."""
+    import numpy as np
+    from oracle import csa_oracle as orc
+    n = min(size, 4096)
+    k = orc.scaled_radar(n, n)
+    rng = np.random.default_rng(0)
+    raw = (rng.standard_normal((n, n), dtype=np.float32) + 1j * rng.standard_normal((n, n), dtype=np.float32))
+    raw = raw.astype(np.complex64)
+    best = 1e30
+    for _ in range(2):
+        t = time.perf_counter()
+        orc.sar_focus_csa_lean(raw, *orc.focus_args(k), workers=1)
+        best = min(best, time.perf_counter() - t)
+    scale = (size / n) ** 2                      # samples per full frame / samples in the sample
+    return {"value": 1.0 / (best * scale), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n}x{n} complex64 noise frame, oracle/csa_oracle.sar_focus_csa_lean (NumPy/scipy.fft, "
+                      f"1 thread of {os.cpu_count()}), {best:.2f} s, scaled x{scale:.0f} by sample count to "
+                      f"{size}x{size}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--unfused", action="store_true", help="run range passes 2 and 3 as two launches")
+    ap.add_argument("--passes", action="store_true", help="also time every pass alone (stderr)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import sarx
+    from sarx import _ffi, radar
+    from sarx.batch import RcclStackComm
+
+    ctx = sarx.Context(local_rank)
+    n = a.size
+    K, W = a.steps, a.warmup
+    flags = 0 if a.unfused else _ffi.FUSE_RANGE
+    plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=flags)
+    d_in, d_img = ctx.alloc(n * n * 8), ctx.alloc(n * n * 8)
+    ctx.fill_noise(d_in, n * n, 1000 + rank)
+
+    comm = d_slot = d_recv = None
+    slot_bytes = (n // LOOKS) * (n // LOOKS) * 4
+    if world > 1:
+        def bootstrap(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = RcclStackComm(ctx, world, rank, bootstrap)
+        d_slot = ctx.alloc(slot_bytes)
+        d_recv = ctx.alloc(slot_bytes * world * 2)        # double-buffered round blocks
+
+    def step(s, mark):
+        if mark and 2 * s + 1 < 256:
+            plan.mark_range(2 * s, 2 * s + 1)
+        else:
+            plan.mark_range(-1, -1)
+        plan.focus_dev(d_in, d_img)
+        if comm is not None:
+            ctx.multilook(d_img, d_slot, n, n, LOOKS)
+            ctx.lib.sarx_allgather_dev(ctx.h, d_slot.ptr, d_recv.ptr + (s & 1) * slot_bytes * world, slot_bytes)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for s in range(W):
+        step(s, False)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(K):
+        step(s, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel = the range pass; events were recorded on the kernel's own stream
+    marked = min(K, 127)
+    rg_ms = sum(ctx.elapsed_ms(2 * s, 2 * s + 1) for s in range(marked)) / max(marked, 1)
+    launches = 1 if not a.unfused else 2
+    alg_bytes = 16.0 * n * n * launches            # one c64 read + one c64 write per sample per launch
+    achieved = alg_bytes / (rg_ms * 1e-3) / 1e9
+
+    import numpy as np
+    probe = d_img.download(np.complex64, (4, n))
+    assert np.isfinite(probe).all() and np.abs(probe).max() > 0, "focused image is not finite / all zero"
+
+    if a.passes and rank == 0:
+        tmp = ctx.alloc(n * n * 8)
+        names = {_ffi.PASS_AZ_FFT_PHI1: "az_fft_phi1(2 launches)", _ffi.PASS_RG_FFT_PHI2: "rg_fft_phi2",
+                 _ffi.PASS_RG_IFFT_PHI3: "rg_ifft_phi3", _ffi.PASS_RG_FUSED_23: "rg_fused_23",
+                 _ffi.PASS_AZ_IFFT: "az_ifft(2 launches)"}
+        for pid, nm in names.items():
+            plan.run_pass(pid, d_in, tmp)
+            ctx.sync()
+            ctx.record(250)
+            for _ in range(5):
+                plan.run_pass(pid, d_in, tmp)
+            ctx.record(251)
+            ms = ctx.elapsed_ms(250, 251) / 5
+            print(f"[pass] {nm:26s} {ms:8.3f} ms  {16.0 * n * n / ms / 1e6:8.1f} GB/s per 16B/sample", file=sys.stderr)
+        tmp.release()
+
+    if rank == 0:
+        line = {
+            "metric": "focused SAR frames/sec (CSA focus, complex64)", "value": world * K / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "c64 (phase arguments f64)", "data": "synthetic",
+            "config": {"workload": f"{n}x{n} complex64 single-channel CSA focus, echo resident in HBM",
+                       "frames_per_step_per_gpu": 1, "range_passes": "fused 2+3" if not a.unfused else "separate",
+                       "image_layout": "[n_az x n_rg]; img.T returned as a view like the reference",
+                       "parallelism": f"frames sharded 1/GPU x{world}" +
+                                      ("; 16x16 multilook + RCCL all-gather of the stack slot per step" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "range_pass_kernel" + ("<fused FFT,Phi2,IFFT,Phi3>" if not a.unfused else "<FFT+Phi2>,<IFFT+Phi3>"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "launch_ms": rg_ms / launches, "algorithmic_bytes_per_launch": 16.0 * n * n},
+        }
+        if world == 1 and not a.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

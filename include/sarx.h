@@ -87,7 +87,7 @@ int sarx_memcpy_d2h(sarx_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 int sarx_memcpy_d2d(sarx_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 int sarx_memset(sarx_ctx* ctx, void* dst_dev, int value, size_t bytes);
 int sarx_sync(sarx_ctx* ctx);
-/* HIP events on the ctx stream: record `slot` (0..63); elapsed ms between two recorded slots */
+/* HIP events on the ctx stream: record `slot` (0..255); elapsed ms between two recorded slots */
 int sarx_event_record(sarx_ctx* ctx, int slot);
 int sarx_event_elapsed_ms(sarx_ctx* ctx, int slot_start, int slot_stop, float* out_ms);
 
@@ -106,6 +106,9 @@ int sarx_csa_focus_host(sarx_plan* plan, const void* phist_host, void* image_hos
 int sarx_csa_focus_dev(sarx_plan* plan, const void* d_phist, void* d_image);
 /* one pass, device to device (d_out may equal d_in only for the range passes) */
 int sarx_csa_pass(sarx_plan* plan, int pass_id, const void* d_in, void* d_out);
+/* profiling hook: sarx_csa_focus_dev records ctx event slots around its range pass(es)
+ * (the roofline kernel); pass -1, -1 to switch off */
+int sarx_csa_plan_mark_range(sarx_plan* plan, int slot_start, int slot_stop);
 /* bytes of HBM scratch the plan holds (two ping-pong images + tables) */
 int sarx_csa_plan_bytes(const sarx_plan* plan, uint64_t* out_bytes);
 

@@ -17,7 +17,7 @@ using namespace sarx;
 
 static thread_local std::string g_init_error;
 static constexpr double C_LIGHT = 299792458.0;     // sar_ati_dcpa_sim_csa.py:211
-static constexpr int N_EVENTS = 64;
+static constexpr int N_EVENTS = 256;
 static constexpr int TW_MAX = 16384;
 
 struct RcclApi {
@@ -76,6 +76,7 @@ struct sarx_plan {
     float2* buf_a = nullptr;           // second scratch (RG_MAJOR only)
     float2 *h_in = nullptr, *h_out = nullptr;   // device staging for the *_host entry point
     uint64_t bytes = 0;
+    int mark_start = -1, mark_stop = -1;   // ctx event slots recorded around the range pass(es)
 };
 
 static int fail(sarx_ctx* c, int code, const char* fmt, ...) {
@@ -292,6 +293,13 @@ int sarx_csa_plan_destroy(sarx_plan* p) {
     return SARX_OK;
 }
 
+int sarx_csa_plan_mark_range(sarx_plan* p, int slot_start, int slot_stop) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    if (slot_start >= N_EVENTS || slot_stop >= N_EVENTS) return fail(p->ctx, SARX_ERR_INVALID, "event slot out of range");
+    p->mark_start = slot_start; p->mark_stop = slot_stop;
+    return SARX_OK;
+}
+
 int sarx_csa_plan_bytes(const sarx_plan* p, uint64_t* out) {
     if (!p || !out) return fail(p ? p->ctx : nullptr, SARX_ERR_INVALID, "NULL argument");
     *out = p->bytes;
@@ -390,6 +398,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     // pass 1: azimuth FFT + Phi_1: phist -> (image as step-A scratch) -> buf_b
     if ((rc = az_pass(p, false, d_phist, d_image, p->buf_b)) != SARX_OK) return rc;
     // passes 2, 3 in place on buf_b
+    if (p->mark_start >= 0) { HIPCHK(c, hipEventRecord(c->ev[p->mark_start], c->stream)); c->ev_set[p->mark_start] = true; }
     if (p->flags & SARX_FUSE_RANGE) {
         RangeArgs a = range_args(p, p->buf_b, p->buf_b);
         HIPCHK(c, launch_range_pass(p->n_rg, RG_FUSED, a, c->stream));
@@ -398,6 +407,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
         HIPCHK(c, launch_range_pass(p->n_rg, RG_FFT_PHI2, a, c->stream));
         HIPCHK(c, launch_range_pass(p->n_rg, RG_IFFT_PHI3, a, c->stream));
     }
+    if (p->mark_stop >= 0) { HIPCHK(c, hipEventRecord(c->ev[p->mark_stop], c->stream)); c->ev_set[p->mark_stop] = true; }
     // pass 4: azimuth IFFT; step A in place on buf_b, step B out to the image (or buf_a before the corner turn)
     float2* last = rg_major ? p->buf_a : (float2*)d_image;
     if (p->az_s == p->n_az) {

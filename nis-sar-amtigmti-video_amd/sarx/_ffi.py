@@ -65,6 +65,7 @@ SIGNATURES = {
     "sarx_csa_focus_host": (_i, [_vp, _vp, _vp]),
     "sarx_csa_focus_dev": (_i, [_vp, _vp, _vp]),
     "sarx_csa_pass": (_i, [_vp, _i, _vp, _vp]),
+    "sarx_csa_plan_mark_range": (_i, [_vp, _i, _i]),
     "sarx_csa_plan_bytes": (_i, [_vp, _P(_u64)]),
     "sarx_ati_dpca_dev": (_i, [_vp, _vp, _vp, _sz, _d, _P(AtiOutputs), _P(_d), _P(_d)]),
     "sarx_mask_phase_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),

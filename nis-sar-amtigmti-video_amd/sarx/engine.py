@@ -197,6 +197,10 @@ class CsaPlan:
         check(self.ctx.lib.sarx_csa_focus_host(self.h, a.ctypes.data, out.ctypes.data), self.ctx.h)
         return out
 
+    def mark_range(self, slot_start=-1, slot_stop=-1):
+        """focus_dev records ctx events around its range pass(es) (roofline kernel timing)."""
+        check(self.ctx.lib.sarx_csa_plan_mark_range(self.h, int(slot_start), int(slot_stop)), self.ctx.h)
+
     def focus_dev(self, d_phist, d_image):
         check(self.ctx.lib.sarx_csa_focus_dev(self.h, d_phist.ptr, d_image.ptr), self.ctx.h)
 

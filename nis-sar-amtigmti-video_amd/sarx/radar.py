@@ -1,0 +1,32 @@
+"""Radar/scene scalars of the reference's two-channel CSA script
+(sar_ati_dcpa_sim_csa.py:18-38,42,68,112,407), as host-side constants."""
+from __future__ import annotations
+
+import math
+
+C = 299792458.0
+
+
+def reference_constants():
+    Re, h, GM = 6371000.0, 350000.0, 3.986004418e14
+    R_sat = Re + h
+    V_sat = math.sqrt(GM / R_sat)                       # :23
+    FC, BW, PRF, T_p, FS = 9.65e9, 500e6, 6000.0, 20e-6, 600e6
+    look = math.radians(45.0)
+    inc = math.asin((R_sat / Re) * math.sin(look))       # :35
+    gamma = inc - look
+    R0 = math.sqrt(Re**2 + R_sat**2 - 2 * Re * R_sat * math.cos(gamma))   # :38
+    return dict(C=C, Re=Re, h=h, R_sat=R_sat, GM=GM, V_sat=V_sat, FC=FC, BW=BW, Lambda=C / FC, PRF=PRF,
+                T_p=T_p, FS=FS, gamma_rad=gamma, R0=R0, V_eff=V_sat * math.sqrt(Re / R_sat),   # :68
+                Kr=BW / T_p, d_rx=2 * V_sat / PRF)                                              # :407, :42
+
+
+def focus_args(n_rg=None, k=None):
+    """Positional arguments of sar_focus_csa after phist (:410) for the reference radar;
+    t_start_fast centres an n_rg-sample window on R0 (:112 uses the 22 us window)."""
+    k = k or reference_constants()
+    if n_rg is None:
+        t0 = 2 * k["R0"] / C - k["T_p"] / 2 - 1e-6       # :112
+    else:
+        t0 = 2 * k["R0"] / C - (n_rg / k["FS"]) / 2
+    return (k["Lambda"], k["T_p"], k["Kr"], k["FS"], k["PRF"], k["V_eff"], k["R0"], t0)
