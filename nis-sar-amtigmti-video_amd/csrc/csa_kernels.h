@@ -37,6 +37,9 @@ struct AzArgs {
 };
 
 hipError_t launch_range_pass(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
+// range_v2.hip: 32 points/thread, split re/im exchange (two lines resident per CU at 16384)
+bool range_v2_supported(int n_rg);
+hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
 // r: FFT length of the tile (2..128), w: tile width in range samples (16 or 32), nq: tiles along azimuth
 hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int nq, hipStream_t st);
 

@@ -4,33 +4,9 @@
 // reference cancel: phases are evaluated at natural-order bins.
 #include "csa_kernels.h"
 #include "fft_core.hpp"
+#include "phase.hpp"
 
 namespace sarx {
-
-// ------------------------------------------------------------------------------
-// phase functions, evaluated in fp64 revolutions (see cis_rev)
-// ------------------------------------------------------------------------------
-// Phi_2[i,k] = exp(j[pi fr_k^2/(Kr(1+Cs_i)) + 4 pi R_ref Cs_i fr_k / c])      (:318-324)
-//   c2[i] = { 0.5/(Kr(1+Cs_i)),  2 R_ref Cs_i / c }
-template <int N> __device__ __forceinline__ cf phi2(int k, double2 c2, double df) {
-    const int ks = (k < N / 2) ? k : k - N;        // fftfreq order
-    const double f = (double)ks * df;
-    return cis_rev(f * fma(c2.x, f, c2.y));
-}
-// Phi_3[i,j] = exp(j[4 pi (c tau_j/2) D_i/lam - pi Kr Cs_i(1+Cs_i)(tau_j - 2R_ref/c)^2])   (:359,375-380)
-//   c3[i] = { c D_i / lam,  -0.5 Kr Cs_i (1+Cs_i) }
-__device__ __forceinline__ cf phi3(int j, double2 c3, double dt, double t_start, double t0) {
-    const double tau = __dadd_rn(t_start, __dmul_rn((double)j, dt));   // :219, unfused like NumPy
-    const double d = tau - t0;
-    return cis_rev(fma(c3.x, tau, c3.y * d * d));
-}
-// Phi_1[i,j] = exp(-j pi Kr Cs_i (tau_j - tau_ref_i)^2)                           (:262-272)
-//   c1[i] = { -0.5 Kr Cs_i, tau_ref_i }
-__device__ __forceinline__ cf phi1(int j, double2 c1, double dt, double t_start) {
-    const double tau = __dadd_rn(t_start, __dmul_rn((double)j, dt));
-    const double d = tau - c1.y;
-    return cis_rev(c1.x * d * d);
-}
 
 // ------------------------------------------------------------------------------
 // range pass: one line (row) per T = N/16 threads, several short lines per workgroup
@@ -72,15 +48,7 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
             for (int r = 0; r < R0; ++r) v[b * R0 + r] = src[E::in_index(t, b, r)];
         stockham_run<N, 1, false, false>(v, t, 0, my_lds, a.tw);
         constexpr int RL = E::R_last;
-        if constexpr (MODE != RG_FFT) {
-            const double2 c2 = a.c2[row];
-#pragma unroll
-            for (int b = 0; b < P / RL; ++b)
-#pragma unroll
-                for (int r = 0; r < RL; ++r)
-                    v[b * RL + r] = cmul(v[b * RL + r], phi2<N>(E::out_index(t, b, r), c2, a.df));
-        }
-        if constexpr (MODE != RG_FUSED) {
+        if constexpr (MODE == RG_FFT) {
             if (live) {
 #pragma unroll
                 for (int b = 0; b < P / RL; ++b)
@@ -88,6 +56,24 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
                     for (int r = 0; r < RL; ++r) dst[E::out_index(t, b, r)] = v[b * RL + r];
             }
             return;
+        } else {
+            // output bin of register (b, r) is t + T*m with m = b + (P/RL)*r; bins >= N/2 are negative frequencies
+            const double2 c2 = a.c2[row];
+            constexpr int B = P / RL;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                FixPhase q = phi2_seed(t + half * (P / 2) * T - half * N, T, c2, a.df);
+#pragma unroll
+                for (int mm = 0; mm < P / 2; ++mm) {
+                    const int m = half * (P / 2) + mm;
+                    const int reg = (m % B) * RL + m / B;
+                    v[reg] = cmul(v[reg], q.next());
+                    if constexpr (MODE == RG_FFT_PHI2) {
+                        if (live) dst[t + T * m] = v[reg];
+                    }
+                }
+            }
+            if constexpr (MODE == RG_FFT_PHI2) return;
         }
     }
     // inverse half.  In the fused pass the registers already hold the first
@@ -111,14 +97,17 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
         for (int i = 0; i < P; ++i) v[i] = make_float2(v[i].x * s, v[i].y * s);
     } else {
         const double2 c3 = a.c3[row];
+        FixPhase q = phi3_seed(t, T, c3, a.dt, a.t_start, a.t0);
+        constexpr int B = P / RL;
 #pragma unroll
-        for (int b = 0; b < P / RL; ++b)
-#pragma unroll
-            for (int r = 0; r < RL; ++r) {
-                cf ph = phi3(EI::out_index(t, b, r), c3, a.dt, a.t_start, a.t0);
-                ph.x *= s; ph.y *= s;
-                v[b * RL + r] = cmul(v[b * RL + r], ph);
-            }
+        for (int m = 0; m < P; ++m) {
+            const int reg = (m % B) * RL + m / B;
+            cf ph = q.next();
+            ph.x *= s; ph.y *= s;
+            const cf y = cmul(v[reg], ph);
+            if (live) dst[t + T * m] = y;
+        }
+        return;
     }
     if (live) {
 #pragma unroll

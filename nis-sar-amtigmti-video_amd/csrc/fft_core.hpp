@@ -232,17 +232,20 @@ template <int N, bool REV> struct Edge {
 };
 
 // ---- phase helpers ---------------------------------------------------------------
-// exp(2*pi*i*p) for a phase p given in revolutions, fp64 in, fp32 out.
-// The argument is reduced in fp64 (|p| reaches 3e7 revolutions in Phi_3), the
-// trigonometry is fp32 on |x| <= 1/8 after a quadrant split.
-__device__ __forceinline__ cf cis_rev(double p) {
-    const double f = p - rint(p);            // [-0.5, 0.5]
-    const float x = (float)f;
+// exp(2*pi*i*f) for f already reduced to [-0.5, 0.5] revolutions.
+//  SARX_HW_SINCOS=1: v_sin_f32 / v_cos_f32 (argument in revolutions, quarter rate)
+//  SARX_HW_SINCOS=0: quadrant split + Taylor polynomials on |x| <= 1/8 (truncation < 2e-9)
+#ifndef SARX_HW_SINCOS
+#define SARX_HW_SINCOS 1
+#endif
+__device__ __forceinline__ cf cis_frac(float x) {
+#if SARX_HW_SINCOS
+    return make_float2(__builtin_amdgcn_cosf(x), __builtin_amdgcn_sinf(x));
+#else
     const float q = rintf(4.0f * x);         // -2..2
     const float r = fmaf(q, -0.25f, x);      // [-1/8, 1/8]
     const float th = 6.28318530717958647692f * r;
     const float t2 = th * th;
-    // Taylor to th^9 / th^8 on |th| <= pi/4: truncation < 2e-9
     float s = fmaf(t2, 2.7557319e-6f, -1.9841270e-4f);
     s = fmaf(s, t2, 8.3333333e-3f);
     s = fmaf(s, t2, -1.6666667e-1f);
@@ -251,11 +254,13 @@ __device__ __forceinline__ cf cis_rev(double p) {
     c = fmaf(c, t2, 4.1666667e-2f);
     c = fmaf(c, t2, -0.5f);
     c = fmaf(c, t2, 1.0f);
-    const int qi = (int)q & 3;
-    // rotate by qi quarter turns
+    const int qi = (int)q & 3;               // rotate by qi quarter turns
     const float cs = (qi & 1) ? -s : c;
     const float sn = (qi & 1) ? c : s;
     return (qi & 2) ? make_float2(-cs, -sn) : make_float2(cs, sn);
+#endif
 }
+// exp(2*pi*i*p) for a phase p in revolutions, fp64 in (|p| reaches 3e7 in Phi_3), fp32 out.
+__device__ __forceinline__ cf cis_rev(double p) { return cis_frac((float)(p - rint(p))); }
 
 }  // namespace sarx

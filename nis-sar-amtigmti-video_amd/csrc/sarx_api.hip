@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +62,7 @@ struct sarx_ctx {
     double* ati_out3 = nullptr;
     ncclComm_t comm = nullptr;
     int n_ranks = 0, rank = 0;
+    int range_impl = 0;                // 0 auto, 1 = 16 pts/thread, 2 = 32 pts/thread split exchange (SARX_RANGE_IMPL)
     std::string err;
 };
 
@@ -129,6 +131,7 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
         return fail(nullptr, SARX_ERR_UNSUPPORTED, "device %d is %s; libsarx is built for gfx950 only", device_id, prop.gcnArchName);
     sarx_ctx* c = new sarx_ctx();
     c->device = device_id;
+    if (const char* e2 = getenv("SARX_RANGE_IMPL")) c->range_impl = (e2[0] == 'v') ? atoi(e2 + 1) : atoi(e2);
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     for (int i = 0; i < N_EVENTS; ++i) HIPCHK(nullptr, hipEventCreate(&c->ev[i]));
@@ -336,6 +339,15 @@ static RangeArgs range_args(const sarx_plan* p, const void* in, void* out) {
     return a;
 }
 
+static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
+    const sarx_ctx* c = p->ctx;
+    // measured on MI355X (profiles/): 32 pts/thread wins for one FFT per launch at n_rg >= 8192,
+    // 16 pts/thread wins for the fused FFT+IFFT launch (the 32-pt form spills there)
+    const bool v2 = range_v2_supported(p->n_rg) &&
+                    (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 8192 && mode != RG_FUSED));
+    return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
+}
+
 // azimuth FFT (+epilogue) in -> out via tmp (tmp unused for single-step sizes); in is not modified
 static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out) {
     sarx_ctx* c = p->ctx;
@@ -379,11 +391,11 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
             if (d_in == d_out || d_in == p->buf_b || d_out == p->buf_b)
                 return fail(c, SARX_ERR_INVALID, "azimuth passes are out-of-place");
             return az_pass(p, pass_id == SARX_PASS_AZ_IFFT, d_in, p->buf_b, d_out);
-        case SARX_PASS_RG_FFT_PHI2: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_FFT_PHI2, a, c->stream)); return SARX_OK; }
-        case SARX_PASS_RG_IFFT_PHI3: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_IFFT_PHI3, a, c->stream)); return SARX_OK; }
-        case SARX_PASS_RG_FUSED_23: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_FUSED, a, c->stream)); return SARX_OK; }
-        case 100: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_FFT, a, c->stream)); return SARX_OK; }   // plain FFT (tests)
-        case 101: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, launch_range_pass(p->n_rg, RG_IFFT, a, c->stream)); return SARX_OK; }  // plain IFFT (tests)
+        case SARX_PASS_RG_FFT_PHI2: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FFT_PHI2, a)); return SARX_OK; }
+        case SARX_PASS_RG_IFFT_PHI3: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_IFFT_PHI3, a)); return SARX_OK; }
+        case SARX_PASS_RG_FUSED_23: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FUSED, a)); return SARX_OK; }
+        case 100: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FFT, a)); return SARX_OK; }   // plain FFT (tests)
+        case 101: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_IFFT, a)); return SARX_OK; }  // plain IFFT (tests)
     }
     return fail(c, SARX_ERR_INVALID, "unknown pass id %d", pass_id);
 }
@@ -401,11 +413,11 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     if (p->mark_start >= 0) { HIPCHK(c, hipEventRecord(c->ev[p->mark_start], c->stream)); c->ev_set[p->mark_start] = true; }
     if (p->flags & SARX_FUSE_RANGE) {
         RangeArgs a = range_args(p, p->buf_b, p->buf_b);
-        HIPCHK(c, launch_range_pass(p->n_rg, RG_FUSED, a, c->stream));
+        HIPCHK(c, run_range(p, RG_FUSED, a));
     } else {
         RangeArgs a = range_args(p, p->buf_b, p->buf_b);
-        HIPCHK(c, launch_range_pass(p->n_rg, RG_FFT_PHI2, a, c->stream));
-        HIPCHK(c, launch_range_pass(p->n_rg, RG_IFFT_PHI3, a, c->stream));
+        HIPCHK(c, run_range(p, RG_FFT_PHI2, a));
+        HIPCHK(c, run_range(p, RG_IFFT_PHI3, a));
     }
     if (p->mark_stop >= 0) { HIPCHK(c, hipEventRecord(c->ev[p->mark_stop], c->stream)); c->ev_set[p->mark_stop] = true; }
     // pass 4: azimuth IFFT; step A in place on buf_b, step B out to the image (or buf_a before the corner turn)

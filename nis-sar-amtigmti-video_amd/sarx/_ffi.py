@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsarx.so")
+LIB_PATH = os.environ.get("SARX_LIB") or os.path.join(_HERE, "libsarx.so")
 
 COMM_ID_BYTES = 128
 OUT_AZ_MAJOR, OUT_RG_MAJOR, FUSE_RANGE = 0, 1, 2
