@@ -1,0 +1,65 @@
+"""VideoSAR batch sharding / stack assembly: unit tests + a world_size-2 gloo run on CPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from sarx import batch
+
+
+def test_shard_frames_round_robin():
+    assert batch.shard_frames(8, 2, 0) == [0, 2, 4, 6]
+    assert batch.shard_frames(8, 2, 1) == [1, 3, 5, 7]
+    assert batch.shard_frames(5, 4, 3) == [3]
+    assert batch.shard_frames(3, 4, 3) == []
+    assert batch.shard_frames(0, 2, 1) == []
+    assert sorted(sum((batch.shard_frames(64, 8, r) for r in range(8)), [])) == list(range(64))
+    with pytest.raises(ValueError):
+        batch.shard_frames(4, 2, 2)
+
+
+def test_stack_from_rounds_orders_and_drops_padding():
+    world, n = 4, 6
+    blocks = []
+    for i in range(batch.rounds(n, world)):
+        blk = np.zeros((world, 2, 2), np.float32)
+        for r in range(world):
+            f = i * world + r
+            blk[r] = f if f < n else -1
+        blocks.append(blk)
+    st = batch.stack_from_rounds(blocks, n)
+    assert st.shape == (6, 2, 2)
+    assert [int(st[f, 0, 0]) for f in range(n)] == list(range(n))
+    norm, g = batch.normalise_stack(st)
+    assert g == 5.0 and norm.max() == 1.0
+    assert batch.normalise_stack(np.zeros((2, 2, 2)))[1] == 1.0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n_frames", [4, 5])
+def test_two_rank_gloo_stack_equals_single_process(tmp_path, n_frames):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_batch_worker.py"), str(tmp_path), str(n_frames)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s0 = np.load(tmp_path / "stack_rank0.npy")
+    s1 = np.load(tmp_path / "stack_rank1.npy")
+    np.testing.assert_array_equal(s0, s1)                    # every rank holds the whole stack
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _batch_worker as w
+    single = np.stack([w.frame_slot(f) for f in range(n_frames)])
+    assert s0.shape == single.shape == (n_frames, 16, 16)
+    np.testing.assert_array_equal(s0, single)                # N-rank stack == 1-rank stack, bit for bit

@@ -228,3 +228,15 @@ def test_errors_are_loud(sx, ctx):
     bad[3] = 0.0
     with pytest.raises(sx.SarxError):
         sx.CsaPlan(ctx, 64, 64, *bad)
+
+
+def test_rccl_allgather_single_rank(sx, ctx):
+    """The RCCL path end to end on one GPU: communicator of one rank, gather = copy, on the comm stream."""
+    from sarx.batch import RcclStackComm
+    x = np.arange(1 << 16, dtype=np.float32)
+    d_s, d_r = ctx.to_device(x), ctx.alloc(x.nbytes)
+    comm = RcclStackComm(ctx, 1, 0, bootstrap=lambda uid: uid)
+    comm.all_gather_dev(d_s, d_r, x.nbytes)
+    comm.finish()
+    np.testing.assert_array_equal(d_r.download(np.float32, x.shape), x)
+    ctx.lib.sarx_comm_destroy(ctx.h)
