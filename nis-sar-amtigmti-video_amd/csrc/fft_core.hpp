@@ -157,6 +157,26 @@ template <int N, int W> struct LdsSize {
     static constexpr int value = (W == 1) ? (N + (N >> 4)) : N * W;   // in cf elements
 };
 
+// Base twiddle of a stage: exp(-+ 2 pi i k / D), D = Ns*R a power of two, k < Ns.
+//  SARX_HW_TWIDDLE=1: v_sin_f32 / v_cos_f32 on the exact fp32 value k/D (in revolutions).  No
+//    memory operation, so the only VMEM traffic of a range kernel is the line itself and a
+//    prefetched next line can stay in flight (vmcnt retires in order: a table load issued after
+//    the prefetch would have to wait for it).
+//  SARX_HW_TWIDDLE=0: fp64-evaluated table tw[m] = exp(-2 pi i m / N).
+#ifndef SARX_HW_TWIDDLE
+#define SARX_HW_TWIDDLE 1
+#endif
+__device__ __forceinline__ cf cis_frac(float x);
+template <int N, int D, bool INV> __device__ __forceinline__ cf stage_twiddle(int k, const cf* __restrict__ tw) {
+#if SARX_HW_TWIDDLE
+    const float x = (float)k * (1.0f / (float)D);          // exact: D is a power of two, k < 2^24
+    return cis_frac(INV ? x : -x);
+#else
+    cf w = tw[k * (N / D)];
+    return INV ? cconj(w) : w;
+#endif
+}
+
 // One Stockham stage on registers.  v holds P points: butterfly b (j = t + b*T)
 // occupies v[b*R .. b*R+R-1].
 template <int N, int T, int R, int NS, bool INV>
@@ -167,9 +187,7 @@ __device__ __forceinline__ void stage_compute(cf* v, int t, const cf* __restrict
     for (int b = 0; b < B; ++b) {
         if constexpr (NS > 1) {
             const int j = t + b * T;
-            cf w = tw[(j % NS) * (N / (NS * R))];
-            if (INV) w = cconj(w);
-            apply_twiddle_powers<R>(v + b * R, w);
+            apply_twiddle_powers<R>(v + b * R, stage_twiddle<N, NS * R, INV>(j % NS, tw));
         }
         dft<R, INV>(v + b * R);
     }
@@ -204,19 +222,33 @@ __device__ __forceinline__ void stage_gather(cf* v, int t, int c, const cf* lds)
 // Runs stages S..nstages-1 of Plan<N> (order REV) on registers that already
 // hold stage S's inputs.  Leaves the last stage's outputs in v: butterfly b,
 // point r is output index  (t + b*T) + r*(N/Rlast).
-template <int N, int W, bool INV, bool REV, int S = 0>
+//
+// WAVE_LOCAL: the whole transform lives in one wavefront (T == 64) and `lds` is
+// a region no other wave touches.  LDS instructions of one wave execute in
+// issue order, so the exchanges need no s_barrier, only a compiler fence; the
+// waves of a workgroup then drift apart and overlap each other's LDS and VALU phases.
+template <bool WAVE_LOCAL> __device__ __forceinline__ void exchange_sync() {
+    if constexpr (WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+template <int N, int W, bool INV, bool REV, int S = 0, bool WAVE_LOCAL = false>
 __device__ __forceinline__ void stockham_run(cf* v, int t, int c, cf* lds, const cf* __restrict__ tw) {
     using PL = Plan<N>;
+    static_assert(!WAVE_LOCAL || PL::T == 64, "wave-local transforms span exactly one wavefront");
     constexpr int R = PL::template radix<REV>(S);
     constexpr int NS = PL::template ns_before<REV>(S);
     stage_compute<N, PL::T, R, NS, INV>(v, t, tw);
     if constexpr (S + 1 < PL::nstages) {
         constexpr int R2 = PL::template radix<REV>(S + 1);
-        if constexpr (S > 0) __syncthreads();             // previous gather done before overwrite
+        if constexpr (S > 0) exchange_sync<WAVE_LOCAL>();   // previous gather done before overwrite
         stage_scatter<N, PL::T, R, NS, W>(v, t, c, lds);
-        __syncthreads();
+        exchange_sync<WAVE_LOCAL>();
         stage_gather<N, PL::T, R2, W>(v, t, c, lds);
-        stockham_run<N, W, INV, REV, S + 1>(v, t, c, lds, tw);
+        stockham_run<N, W, INV, REV, S + 1, WAVE_LOCAL>(v, t, c, lds, tw);
     }
 }
 

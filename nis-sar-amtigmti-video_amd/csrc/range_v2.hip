@@ -58,9 +58,7 @@ __device__ __forceinline__ void v2_compute(cf* v, int t, const cf* __restrict__ 
     for (int b = 0; b < B; ++b) {
         if constexpr (NS > 1) {
             const int j = V2<N>::j(t, b);
-            cf w = tw[(j % NS) * (N / (NS * R))];
-            if (INV) w = cconj(w);
-            apply_twiddle_powers<R>(v + b * R, w);
+            apply_twiddle_powers<R>(v + b * R, stage_twiddle<N, NS * R, INV>(j % NS, tw));
         }
         dft<R, INV>(v + b * R);
     }

@@ -245,6 +245,7 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
     p->ctx = c; p->n_az = n_az; p->n_rg = n_rg; p->flags = flags; p->p = *prm;
     p->az_s = (n_az <= 128) ? n_az : (1 << (ilog2(n_az) / 2));
     p->az_w = (n_rg % 32 == 0) ? 32 : 16;
+    if (const char* e = getenv("SARX_AZ_W")) { const int w = atoi(e); if ((w == 16 || w == 32 || w == 64) && n_rg % w == 0) p->az_w = w; }
 
     // migration factors, natural fftfreq order (sar_ati_dcpa_sim_csa.py:225,244-249,262)
     const double lam = prm->wavelength_m, Kr = prm->chirp_rate_hz_s, Vr = prm->platform_speed_mps, Rref = prm->range_ref_m;
@@ -336,6 +337,7 @@ static RangeArgs range_args(const sarx_plan* p, const void* in, void* out) {
     a.t0 = 2.0 * p->p.range_ref_m / C_LIGHT;
     a.inv_n = 1.0f / (float)p->n_rg;
     a.n_az = p->n_az;
+    if (const char* e = getenv("SARX_DEBUG")) a.debug = atoi(e);
     return a;
 }
 
@@ -345,6 +347,10 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
     // 16 pts/thread wins for the fused FFT+IFFT launch (the 32-pt form spills there)
     const bool v2 = range_v2_supported(p->n_rg) &&
                     (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 8192 && mode != RG_FUSED));
+    // impl 3: fused launch with wave-private sub-transforms; impl 4: persistent + register prefetch
+    if (mode == RG_FUSED && range_fused_wl_supported(p->n_rg) && (c->range_impl == 3 || c->range_impl == 0))
+        return launch_range_fused_wl(a, c->stream);
+    if (range_pf_supported(p->n_rg) && c->range_impl == 4) return launch_range_pass_pf(p->n_rg, mode, a, c->stream);
     return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
 }
 

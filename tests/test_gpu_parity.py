@@ -230,6 +230,34 @@ def test_errors_are_loud(sx, ctx):
         sx.CsaPlan(ctx, 64, 64, *bad)
 
 
+@pytest.mark.parametrize("n_az,n_rg", [(64, 16384), (32, 8192), (16384, 16), (8192, 32)])
+def test_longest_lines_each_pass(sx, ctx, n_az, n_rg):
+    """The kernels the 16384^2 benchmark actually runs (32-point/thread range pass, fused
+    wave-private range pass, 128x128 four-step azimuth pass), on a thin scene the oracle can hold."""
+    from sarx import _ffi
+    raw = _rand((n_az, n_rg), 99)
+    k = orc.scaled_radar(n_az, n_rg)
+    args = orc.focus_args(k)
+    _, _, _, (s1, s2, s3, s4) = orc.sar_focus_csa(raw, *args, return_stages=True)
+    plan = _plan(sx, ctx, n_az, n_rg, args)
+    d_a, d_b = ctx.alloc(raw.nbytes), ctx.alloc(raw.nbytes)
+
+    def run(pid, src):
+        d_a.upload(src.astype(np.complex64))
+        plan.run_pass(pid, d_a, d_b)
+        return d_b.download(np.complex64, (n_az, n_rg))
+
+    assert orc.rel_l2(run(_ffi.PASS_AZ_FFT_PHI1, raw), s1) < 5e-6
+    assert orc.rel_l2(run(_ffi.PASS_RG_FFT_PHI2, s1), s2) < 5e-6
+    assert orc.rel_l2(run(_ffi.PASS_RG_IFFT_PHI3, s2), s3) < 5e-6
+    assert orc.rel_l2(run(_ffi.PASS_RG_FUSED_23, s1), s3) < 5e-6
+    assert orc.rel_l2(run(_ffi.PASS_AZ_IFFT, s3), s4) < 5e-6
+    for fuse in (True, False):
+        img = sx.sar_focus_csa(raw, *args, fuse_range=fuse)[0]
+        assert orc.rel_l2(img, s4.T) < 1e-5
+    plan.close()
+
+
 def test_rccl_allgather_single_rank(sx, ctx):
     """The RCCL path end to end on one GPU: communicator of one rank, gather = copy, on the comm stream."""
     from sarx.batch import RcclStackComm
