@@ -131,12 +131,14 @@ def main():
     probe = d_img.download(np.complex64, (4, n))
     assert np.isfinite(probe).all() and np.abs(probe).max() > 0, "focused image is not finite / all zero"
 
-    if a.passes and rank == 0:
+    # every pass alone, after the timed region (HIP events on the ctx stream, 5 launches each)
+    per_pass = {}
+    if rank == 0 and world == 1:
         tmp = ctx.alloc(n * n * 8)
-        names = {_ffi.PASS_AZ_FFT_PHI1: "az_fft_phi1(2 launches)", _ffi.PASS_RG_FFT_PHI2: "rg_fft_phi2",
-                 _ffi.PASS_RG_IFFT_PHI3: "rg_ifft_phi3", _ffi.PASS_RG_FUSED_23: "rg_fused_23",
-                 _ffi.PASS_AZ_IFFT: "az_ifft(2 launches)"}
-        for pid, nm in names.items():
+        names = {_ffi.PASS_AZ_FFT_PHI1: ("az_fft_phi1", 2), _ffi.PASS_RG_FFT_PHI2: ("rg_fft_phi2", 1),
+                 _ffi.PASS_RG_IFFT_PHI3: ("rg_ifft_phi3", 1), _ffi.PASS_RG_FUSED_23: ("rg_fused_fft_phi2_ifft_phi3", 1),
+                 _ffi.PASS_AZ_IFFT: ("az_ifft", 2)}
+        for pid, (nm, launches_) in names.items():
             plan.run_pass(pid, d_in, tmp)
             ctx.sync()
             ctx.record(250)
@@ -144,8 +146,22 @@ def main():
                 plan.run_pass(pid, d_in, tmp)
             ctx.record(251)
             ms = ctx.elapsed_ms(250, 251) / 5
-            print(f"[pass] {nm:26s} {ms:8.3f} ms  {16.0 * n * n / ms / 1e6:8.1f} GB/s per 16B/sample", file=sys.stderr)
+            per_pass[nm] = {"ms": round(ms, 4), "launches": launches_,
+                            "GBps_per_launch": round(16.0 * n * n * launches_ / ms / 1e6, 1)}
+            if a.passes:
+                print(f"[pass] {nm:30s} {ms:8.3f} ms  {launches_} launch(es)  "
+                      f"{16.0 * n * n * launches_ / ms / 1e6:8.1f} GB/s per launch at 16 B/sample", file=sys.stderr)
         tmp.release()
+
+    # HBM bytes per launch from PMC counters (collected in separate rocprofv3 --pmc runs, see the file)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if n == 16384 and not a.unfused:
+            traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "range_fused_wl" in k)
+    except (OSError, StopIteration, KeyError, ValueError):
+        traffic = None
 
     if rank == 0:
         line = {
@@ -157,10 +173,21 @@ def main():
                        "image_layout": "[n_az x n_rg]; img.T returned as a view like the reference",
                        "parallelism": f"frames sharded 1/GPU x{world}" +
                                       ("; 16x16 multilook + RCCL all-gather of the stack slot per step" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "range_pass_kernel" + ("<fused FFT,Phi2,IFFT,Phi3>" if not a.unfused else "<FFT+Phi2>,<IFFT+Phi3>"),
+            "roofline": {"bound": "hbm", "kernel": ("range_fused_wl_kernel<false> (FFT.Phi2.IFFT.Phi3, one HBM round trip)"
+                                                    if (not a.unfused and n == 16384) else
+                                                    "range_pass_kernel<fused>" if not a.unfused else
+                                                    "range_pass_v2_kernel<FFT+Phi2>, <IFFT+Phi3>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "launch_ms": rg_ms / launches, "algorithmic_bytes_per_launch": 16.0 * n * n},
+                         "traffic": traffic, "launch_ms": rg_ms / launches, "algorithmic_bytes_per_launch": 16.0 * n * n},
         }
+        if per_pass:
+            # the standalone range FFT + Phi_2 launch BASELINE.json's 70 % target names, and the others
+            p2 = per_pass["rg_fft_phi2"]
+            line["roofline_rg_fft_phi2_pass"] = {
+                "bound": "hbm", "achieved": p2["GBps_per_launch"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": p2["GBps_per_launch"] / HBM_PEAK_GBS, "launch_ms": p2["ms"],
+                "note": "same launch outside the timed region; the default path runs it fused with pass 3"}
+            line["passes"] = per_pass
         if world == 1 and not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(line), flush=True)

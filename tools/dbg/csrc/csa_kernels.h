@@ -1,0 +1,79 @@
+// Internal launch interface between the C ABI (sarx_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace sarx {
+
+enum RangeMode { RG_FFT = 0, RG_IFFT = 1, RG_FFT_PHI2 = 2, RG_IFFT_PHI3 = 3, RG_FUSED = 4 };
+enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_SCALE = 3 };
+
+struct RangeArgs {
+    const float2* in;
+    float2* out;
+    const float2* tw;     // exp(-2 pi i m / n_rg), m < n_rg
+    const double2* c2;    // per azimuth bin: {0.5/(Kr(1+Cs)), 2 R_ref Cs / c}
+    const double2* c3;    // per azimuth bin: {c D / lam, -0.5 Kr Cs (1+Cs)}
+    double df;            // 1/(n_rg*dt): fftfreq step (numpy.fft.fftfreq)
+    double dt;            // 1/fs
+    double t_start;       // t_start_fast
+    double t0;            // 2 R_ref / c
+    float inv_n;          // 1/n_rg
+    int n_az;
+    int debug;            // ablation bits for timing experiments (SARX_DEBUG); 0 in production
+};
+
+struct AzArgs {
+    const float2* in;
+    float2* out;
+    const float2* tw_r;   // exp(-2 pi i m / R), m < R      (in-tile FFT)
+    const float2* tw_n;   // exp(-2 pi i m / n_az), m < n_az (four-step twiddle)
+    const double2* c1;    // per azimuth bin: {-0.5 Kr Cs, tau_ref}
+    double dt, t_start;
+    float scale;          // 1/n_az for the inverse's last step
+    int n_rg;
+    // row of tile element m for tile q: q*q_stride + m*m_stride
+    int in_q_stride, in_m_stride, out_q_stride, out_m_stride;
+};
+
+hipError_t launch_range_pass(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
+// range_v2.hip: 32 points/thread, split re/im exchange (two lines resident per CU at 16384)
+bool range_v2_supported(int n_rg);
+hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
+// range_pf.hip: 16 points/thread, persistent workgroups that prefetch the next line into registers
+bool range_pf_supported(int n_rg);
+hipError_t launch_range_pass_pf(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
+// range_fused_wl.hip: fused FFT.Phi2.IFFT.Phi3 at 16384 with wave-private sub-transforms
+bool range_fused_wl_supported(int n_rg);
+hipError_t launch_range_fused_wl(const RangeArgs& a, hipStream_t st);
+// r: FFT length of the tile (2..128), w: tile width in range samples (16 or 32), nq: tiles along azimuth
+hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int nq, hipStream_t st);
+
+// products.hip
+struct AtiArgs {
+    const float2* s1;
+    const float2* s2;
+    size_t n;
+    float cal_c, cal_s;   // exp(i*cal_phase)
+    float* ati_phase;
+    float* mag1;
+    float* dpca_mag;
+    float2* interf;
+    float2* diff;
+    float* mag2;
+    float* ph1;
+    float* ph2;
+    float* dpca_phase;
+    float* part_max;      // [blocks]
+    double2* part_sum;    // [blocks]
+};
+int ati_blocks(size_t n);
+hipError_t launch_ati_dpca(const AtiArgs& a, hipStream_t st);
+hipError_t launch_ati_finish(const float* part_max, const double2* part_sum, int blocks, double* out3, hipStream_t st);
+hipError_t launch_mask_phase(const float* phase, const float* mag, size_t n, float thr, float* out, hipStream_t st);
+hipError_t launch_corner_turn(const float2* in, float2* out, int rows, int cols, hipStream_t st);
+hipError_t launch_multilook(const float2* in, float* out, int rows, int cols, int looks, hipStream_t st);
+hipError_t launch_fill_noise(float2* buf, size_t n, uint64_t seed, hipStream_t st);
+
+}  // namespace sarx

@@ -1,0 +1,268 @@
+// CSA focusing kernels for gfx950: range (row) passes and azimuth (column-tile)
+// passes, each an FFT fused with the phase multiply that follows it in the
+// reference (sar_ati_dcpa_sim_csa.py:233-385).  fftshift/ifftshift pairs of the
+// reference cancel: phases are evaluated at natural-order bins.
+#include "csa_kernels.h"
+#include "fft_core.hpp"
+#include "phase.hpp"
+
+namespace sarx {
+
+// ------------------------------------------------------------------------------
+// range pass: one line (row) per T = N/16 threads, several short lines per workgroup
+// ------------------------------------------------------------------------------
+template <int N> struct RangeCfg {
+    using PL = Plan<N>;
+    static constexpr int T = PL::T;
+    static constexpr int ROWS = (T >= 256) ? 1 : 256 / T;
+    static constexpr int THREADS = T * ROWS;
+    static constexpr int LDS_PER_ROW = LdsSize<N, 1>::value;   // cf elements
+    static constexpr size_t LDS_BYTES = (size_t)ROWS * LDS_PER_ROW * sizeof(cf);
+};
+
+template <int N, int MODE>
+__global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeArgs a) {
+    using CFG = RangeCfg<N>;
+    using PL = Plan<N>;
+    constexpr int P = PL::P, T = PL::T;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+
+    const int r_in_wg = threadIdx.x / T;
+    const int t = threadIdx.x % T;
+    int row = blockIdx.x * CFG::ROWS + r_in_wg;
+    const bool live = row < a.n_az;
+    if (!live) row = a.n_az - 1;                    // keep barriers uniform
+    cf* my_lds = lds + r_in_wg * CFG::LDS_PER_ROW;
+    const cf* __restrict__ src = a.in + (size_t)row * N;
+    cf* __restrict__ dst = a.out + (size_t)row * N;
+
+    constexpr bool FWD_FIRST = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED);
+    cf v[P];
+    if constexpr (FWD_FIRST) {
+        using E = Edge<N, false>;
+        constexpr int R0 = E::R_first;
+#pragma unroll
+        for (int b = 0; b < P / R0; ++b)
+#pragma unroll
+            for (int r = 0; r < R0; ++r)
+                v[b * R0 + r] = (a.debug & 1) ? make_float2(t * 0.001f + r, b - t * 0.002f) : src[E::in_index(t, b, r)];
+        stockham_run<N, 1, false, false>(v, t, 0, my_lds, a.tw);
+        constexpr int RL = E::R_last;
+        if constexpr (MODE == RG_FFT) {
+            if (live) {
+#pragma unroll
+                for (int b = 0; b < P / RL; ++b)
+#pragma unroll
+                    for (int r = 0; r < RL; ++r) dst[E::out_index(t, b, r)] = v[b * RL + r];
+            }
+            return;
+        } else {
+            // output bin of register (b, r) is t + T*m with m = b + (P/RL)*r; bins >= N/2 are negative frequencies
+            const double2 c2 = a.c2[row];
+            constexpr int B = P / RL;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                FixPhase q = phi2_seed(t + half * (P / 2) * T - half * N, T, c2, a.df);
+#pragma unroll
+                for (int mm = 0; mm < P / 2; ++mm) {
+                    const int m = half * (P / 2) + mm;
+                    const int reg = (m % B) * RL + m / B;
+                    v[reg] = cmul(v[reg], q.next());
+                    if constexpr (MODE == RG_FFT_PHI2) {
+                        if (live && (!(a.debug & 2) || v[reg].x == 1.2345e-30f)) dst[t + T * m] = v[reg];
+                    }
+                }
+            }
+            if constexpr (MODE == RG_FFT_PHI2) return;
+        }
+    }
+    // inverse half.  In the fused pass the registers already hold the first
+    // inverse stage's inputs (plan reversed: remainder radix first).
+    constexpr bool REV = (MODE == RG_FUSED);
+    using EI = Edge<N, REV>;
+    if constexpr (!FWD_FIRST) {
+        constexpr int R0 = EI::R_first;
+#pragma unroll
+        for (int b = 0; b < P / R0; ++b)
+#pragma unroll
+            for (int r = 0; r < R0; ++r) v[b * R0 + r] = src[EI::in_index(t, b, r)];
+    } else {
+        __syncthreads();      // forward half's last gather finished before the image is reused
+    }
+    stockham_run<N, 1, true, REV>(v, t, 0, my_lds, a.tw);
+    constexpr int RL = EI::R_last;
+    const float s = a.inv_n;
+    if constexpr (MODE == RG_IFFT) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) v[i] = make_float2(v[i].x * s, v[i].y * s);
+    } else {
+        const double2 c3 = a.c3[row];
+        FixPhase q = phi3_seed(t, T, c3, a.dt, a.t_start, a.t0);
+        constexpr int B = P / RL;
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            const int reg = (m % B) * RL + m / B;
+            cf ph = q.next();
+            ph.x *= s; ph.y *= s;
+            const cf y = cmul(v[reg], ph);
+            if (live) dst[t + T * m] = y;
+        }
+        return;
+    }
+    if (live) {
+#pragma unroll
+        for (int b = 0; b < P / RL; ++b)
+#pragma unroll
+            for (int r = 0; r < RL; ++r) dst[EI::out_index(t, b, r)] = v[b * RL + r];
+    }
+}
+
+template <int N, int MODE> static hipError_t launch_range(const RangeArgs& a, hipStream_t st) {
+    using CFG = RangeCfg<N>;
+    auto k = range_pass_kernel<N, MODE>;
+    if (CFG::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CFG::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    const int grid = (a.n_az + CFG::ROWS - 1) / CFG::ROWS;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(CFG::THREADS), CFG::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+
+template <int N> static hipError_t launch_range_mode(int mode, const RangeArgs& a, hipStream_t st) {
+    switch (mode) {
+        case RG_FFT: return launch_range<N, RG_FFT>(a, st);
+        case RG_IFFT: return launch_range<N, RG_IFFT>(a, st);
+        case RG_FFT_PHI2: return launch_range<N, RG_FFT_PHI2>(a, st);
+        case RG_IFFT_PHI3: return launch_range<N, RG_IFFT_PHI3>(a, st);
+        case RG_FUSED: return launch_range<N, RG_FUSED>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_range_pass(int n_rg, int mode, const RangeArgs& a, hipStream_t st) {
+    switch (n_rg) {
+        case 16: return launch_range_mode<16>(mode, a, st);
+        case 32: return launch_range_mode<32>(mode, a, st);
+        case 64: return launch_range_mode<64>(mode, a, st);
+        case 128: return launch_range_mode<128>(mode, a, st);
+        case 256: return launch_range_mode<256>(mode, a, st);
+        case 512: return launch_range_mode<512>(mode, a, st);
+        case 1024: return launch_range_mode<1024>(mode, a, st);
+        case 2048: return launch_range_mode<2048>(mode, a, st);
+        case 4096: return launch_range_mode<4096>(mode, a, st);
+        case 8192: return launch_range_mode<8192>(mode, a, st);
+        case 16384: return launch_range_mode<16384>(mode, a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------
+// azimuth tile pass: [R rows x W cols] tile, FFT of length R along the rows of
+// each column.  Rows of the tile are  in_base + m*in_stride  of the image, so a
+// long azimuth FFT (n_az = R_A * R_B) is two such launches (four-step) with the
+// inter-step twiddle and the row permutation folded into the addressing:
+//   step A: q in [0,S):   rows q + m*S (m < R_A = n/S)  -> same rows, * W_n^(+-q*m_out)
+//   step B: q in [0,n/S): rows q*S + m (m < S)          -> rows q + m_out*(n/S), * Phi_1 | * 1/n
+// Every global access is a W*8-byte contiguous row segment.
+// ------------------------------------------------------------------------------
+template <int R, int W> struct AzCfg {
+    using PL = Plan<R>;
+    static constexpr int TPC = PL::T;                 // threads per column
+    static constexpr int THREADS = TPC * W;
+    static constexpr size_t LDS_BYTES = (PL::nstages > 1) ? (size_t)LdsSize<R, W>::value * sizeof(cf) : 0;
+};
+
+template <int R, int W, bool INV, int EPI>
+__global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs a) {
+    using PL = Plan<R>;
+    using E = Edge<R, false>;
+    constexpr int P = PL::P;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+
+    const int c = threadIdx.x % W;
+    const int t = threadIdx.x / W;
+    const int col = blockIdx.x * W + c;
+    const int q = blockIdx.y;
+    const size_t in_base = (size_t)q * a.in_q_stride;
+    const size_t out_base = (size_t)q * a.out_q_stride;
+
+    cf v[P];
+    constexpr int R0 = E::R_first;
+#pragma unroll
+    for (int b = 0; b < P / R0; ++b)
+#pragma unroll
+        for (int r = 0; r < R0; ++r) {
+            const size_t rowi = in_base + (size_t)E::in_index(t, b, r) * a.in_m_stride;
+            v[b * R0 + r] = a.in[rowi * a.n_rg + col];
+        }
+    stockham_run<R, W, INV, false>(v, t, c, lds, a.tw_r);
+    constexpr int RL = E::R_last;
+#pragma unroll
+    for (int b = 0; b < P / RL; ++b)
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const int m = E::out_index(t, b, r);
+            const size_t rowo = out_base + (size_t)m * a.out_m_stride;
+            cf x = v[b * RL + r];
+            if constexpr (EPI == AZ_EPI_TWIDDLE) {
+                cf w = a.tw_n[(size_t)q * m];          // q*m < n_az
+                if (INV) w = cconj(w);
+                x = cmul(x, w);
+            } else if constexpr (EPI == AZ_EPI_PHI1) {
+                x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
+            } else if constexpr (EPI == AZ_EPI_SCALE) {
+                x.x *= a.scale; x.y *= a.scale;
+            }
+            a.out[rowo * a.n_rg + col] = x;
+        }
+}
+
+template <int R, int W, bool INV, int EPI> static hipError_t launch_az_one(const AzArgs& a, int nq, hipStream_t st) {
+    using CFG = AzCfg<R, W>;
+    dim3 grid(a.n_rg / W, nq);
+    hipLaunchKernelGGL((az_tile_kernel<R, W, INV, EPI>), grid, dim3(CFG::THREADS), CFG::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const AzArgs& a, int nq, hipStream_t st) {
+    if (!inv) {
+        switch (epi) {
+            case AZ_EPI_NONE: return launch_az_one<R, W, false, AZ_EPI_NONE>(a, nq, st);
+            case AZ_EPI_TWIDDLE: return launch_az_one<R, W, false, AZ_EPI_TWIDDLE>(a, nq, st);
+            case AZ_EPI_PHI1: return launch_az_one<R, W, false, AZ_EPI_PHI1>(a, nq, st);
+        }
+    } else {
+        switch (epi) {
+            case AZ_EPI_NONE: return launch_az_one<R, W, true, AZ_EPI_NONE>(a, nq, st);
+            case AZ_EPI_TWIDDLE: return launch_az_one<R, W, true, AZ_EPI_TWIDDLE>(a, nq, st);
+            case AZ_EPI_SCALE: return launch_az_one<R, W, true, AZ_EPI_SCALE>(a, nq, st);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+template <int R> static hipError_t launch_az_r(int w, bool inv, int epi, const AzArgs& a, int nq, hipStream_t st) {
+    switch (w) {
+        case 16: return launch_az_rw<R, 16>(inv, epi, a, nq, st);
+        case 32: return launch_az_rw<R, 32>(inv, epi, a, nq, st);
+        case 64: return launch_az_rw<R, 64>(inv, epi, a, nq, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int nq, hipStream_t st) {
+    switch (r) {
+        case 2: return launch_az_r<2>(w, inv, epi, a, nq, st);
+        case 4: return launch_az_r<4>(w, inv, epi, a, nq, st);
+        case 8: return launch_az_r<8>(w, inv, epi, a, nq, st);
+        case 16: return launch_az_r<16>(w, inv, epi, a, nq, st);
+        case 32: return launch_az_r<32>(w, inv, epi, a, nq, st);
+        case 64: return launch_az_r<64>(w, inv, epi, a, nq, st);
+        case 128: return launch_az_r<128>(w, inv, epi, a, nq, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace sarx

@@ -1,0 +1,259 @@
+// Element-wise / streaming kernels around the CSA focus: the ATI interferogram +
+// DPCA difference products (sar_ati_dcpa_sim_csa.py:414-419, viewer :42-52), the
+// magnitude mask (:447-449), the LDS corner turn, multilook and noise fill.
+// All are HBM-bound: 16-byte accesses per lane, grid-stride, no MFMA.
+#include "csa_kernels.h"
+
+namespace sarx {
+
+typedef float2 cf;
+static constexpr int ATI_THREADS = 256;
+static constexpr int ATI_MAX_BLOCKS = 4096;
+
+int ati_blocks(size_t n) {
+    size_t pairs = (n + 1) / 2;
+    size_t b = (pairs + ATI_THREADS - 1) / ATI_THREADS;
+    if (b > ATI_MAX_BLOCKS) b = ATI_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+struct Pix {
+    float phase, m1, dm, m2, p1, p2, dp;
+    cf interf, diff;
+    double sre, sim;
+};
+
+template <bool OPT> __device__ __forceinline__ void ati_pixel(cf a, cf b, float cc, float cs, Pix& o) {
+    // uncalibrated interferogram feeds the phase-balance sum (viewer :249)
+    o.sre = (double)a.x * b.x + (double)a.y * b.y;
+    o.sim = (double)a.y * b.x - (double)a.x * b.y;
+    const cf bc = make_float2(b.x * cc - b.y * cs, b.x * cs + b.y * cc);   // s2 * exp(i cal)  (viewer :43)
+    const cf in = make_float2(fmaf(a.x, bc.x, a.y * bc.y), fmaf(a.y, bc.x, -a.x * bc.y));   // a * conj(bc)  (:414)
+    const cf df = make_float2(a.x - bc.x, a.y - bc.y);                                     // (:418)
+    o.phase = atan2f(in.y, in.x);      // (:415)
+    o.m1 = hypotf(a.x, a.y);           // (:416)
+    o.dm = hypotf(df.x, df.y);         // (:419)
+    o.interf = in;
+    o.diff = df;
+    if (OPT) {
+        o.m2 = hypotf(bc.x, bc.y);
+        o.p1 = atan2f(a.y, a.x);
+        o.p2 = atan2f(bc.y, bc.x);
+        o.dp = atan2f(df.y, df.x);
+    }
+}
+
+template <bool OPT> __global__ __launch_bounds__(ATI_THREADS) void ati_dpca_kernel(AtiArgs a) {
+    const size_t npair = a.n / 2;
+    const size_t stride = (size_t)gridDim.x * ATI_THREADS;
+    float vmax = 0.f;
+    double sre = 0.0, sim = 0.0;
+    const float4* s1 = reinterpret_cast<const float4*>(a.s1);
+    const float4* s2 = reinterpret_cast<const float4*>(a.s2);
+    for (size_t i = (size_t)blockIdx.x * ATI_THREADS + threadIdx.x; i < npair; i += stride) {
+        const float4 x = s1[i], y = s2[i];
+        Pix p0, p1;
+        ati_pixel<OPT>(make_float2(x.x, x.y), make_float2(y.x, y.y), a.cal_c, a.cal_s, p0);
+        ati_pixel<OPT>(make_float2(x.z, x.w), make_float2(y.z, y.w), a.cal_c, a.cal_s, p1);
+        reinterpret_cast<float2*>(a.ati_phase)[i] = make_float2(p0.phase, p1.phase);
+        reinterpret_cast<float2*>(a.mag1)[i] = make_float2(p0.m1, p1.m1);
+        reinterpret_cast<float2*>(a.dpca_mag)[i] = make_float2(p0.dm, p1.dm);
+        if (OPT) {
+            if (a.interf) reinterpret_cast<float4*>(a.interf)[i] = make_float4(p0.interf.x, p0.interf.y, p1.interf.x, p1.interf.y);
+            if (a.diff) reinterpret_cast<float4*>(a.diff)[i] = make_float4(p0.diff.x, p0.diff.y, p1.diff.x, p1.diff.y);
+            if (a.mag2) reinterpret_cast<float2*>(a.mag2)[i] = make_float2(p0.m2, p1.m2);
+            if (a.ph1) reinterpret_cast<float2*>(a.ph1)[i] = make_float2(p0.p1, p1.p1);
+            if (a.ph2) reinterpret_cast<float2*>(a.ph2)[i] = make_float2(p0.p2, p1.p2);
+            if (a.dpca_phase) reinterpret_cast<float2*>(a.dpca_phase)[i] = make_float2(p0.dp, p1.dp);
+        }
+        vmax = fmaxf(vmax, fmaxf(p0.m1, p1.m1));
+        sre += p0.sre + p1.sre;
+        sim += p0.sim + p1.sim;
+    }
+    if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd tail pixel
+        const size_t i = a.n - 1;
+        Pix p;
+        ati_pixel<OPT>(a.s1[i], a.s2[i], a.cal_c, a.cal_s, p);
+        a.ati_phase[i] = p.phase; a.mag1[i] = p.m1; a.dpca_mag[i] = p.dm;
+        if (OPT) {
+            if (a.interf) a.interf[i] = p.interf;
+            if (a.diff) a.diff[i] = p.diff;
+            if (a.mag2) a.mag2[i] = p.m2;
+            if (a.ph1) a.ph1[i] = p.p1;
+            if (a.ph2) a.ph2[i] = p.p2;
+            if (a.dpca_phase) a.dpca_phase[i] = p.dp;
+        }
+        vmax = fmaxf(vmax, p.m1); sre += p.sre; sim += p.sim;
+    }
+    // wave (64 lanes) then block reduction
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+        sre += __shfl_down(sre, off, 64);
+        sim += __shfl_down(sim, off, 64);
+    }
+    __shared__ float smax[ATI_THREADS / 64];
+    __shared__ double sr[ATI_THREADS / 64], si[ATI_THREADS / 64];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smax[w] = vmax; sr[w] = sre; si[w] = sim; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < ATI_THREADS / 64; ++k) { vmax = fmaxf(vmax, smax[k]); sre += sr[k]; sim += si[k]; }
+        a.part_max[blockIdx.x] = vmax;
+        a.part_sum[blockIdx.x] = make_double2(sre, sim);
+    }
+}
+
+hipError_t launch_ati_dpca(const AtiArgs& a, hipStream_t st) {
+    const int blocks = ati_blocks(a.n);
+    const bool opt = a.interf || a.diff || a.mag2 || a.ph1 || a.ph2 || a.dpca_phase;
+    if (opt) hipLaunchKernelGGL(ati_dpca_kernel<true>, dim3(blocks), dim3(ATI_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(ati_dpca_kernel<false>, dim3(blocks), dim3(ATI_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+// fixed-order final reduction (bitwise reproducible): out3 = {max, sum_re, sum_im}
+__global__ void ati_finish_kernel(const float* part_max, const double2* part_sum, int blocks, double* out3) {
+    __shared__ float smax[256];
+    __shared__ double sr[256], si[256];
+    float m = 0.f;
+    double re = 0.0, im = 0.0;
+    for (int i = threadIdx.x; i < blocks; i += 256) {
+        m = fmaxf(m, part_max[i]);
+        re += part_sum[i].x;
+        im += part_sum[i].y;
+    }
+    smax[threadIdx.x] = m; sr[threadIdx.x] = re; si[threadIdx.x] = im;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+            sr[threadIdx.x] += sr[threadIdx.x + s];
+            si[threadIdx.x] += si[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out3[0] = (double)smax[0]; out3[1] = sr[0]; out3[2] = si[0]; }
+}
+hipError_t launch_ati_finish(const float* part_max, const double2* part_sum, int blocks, double* out3, hipStream_t st) {
+    hipLaunchKernelGGL(ati_finish_kernel, dim3(1), dim3(256), 0, st, part_max, part_sum, blocks, out3);
+    return hipGetLastError();
+}
+
+// ati_phase[~(mag > thr)] = 0   (sar_ati_dcpa_sim_csa.py:447-449)
+__global__ __launch_bounds__(256) void mask_phase_kernel(const float* phase, const float* mag, size_t n, float thr, float* out) {
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 p = reinterpret_cast<const float4*>(phase)[i];
+        const float4 m = reinterpret_cast<const float4*>(mag)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(m.x > thr ? p.x : 0.f, m.y > thr ? p.y : 0.f,
+                                                        m.z > thr ? p.z : 0.f, m.w > thr ? p.w : 0.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        out[i] = mag[i] > thr ? phase[i] : 0.f;
+    }
+}
+hipError_t launch_mask_phase(const float* phase, const float* mag, size_t n, float thr, float* out, hipStream_t st) {
+    size_t b = (n / 4 + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(mask_phase_kernel, dim3((unsigned)b), dim3(256), 0, st, phase, mag, n, thr, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------
+// corner turn: out[c][r] = in[r][c].  64x64 complex64 tiles staged through a
+// padded LDS image; both the read and the write are 512-byte row segments.
+// ------------------------------------------------------------------------------
+static constexpr int CT = 64;
+__global__ __launch_bounds__(256) void corner_turn_kernel(const cf* __restrict__ in, cf* __restrict__ out, int rows, int cols) {
+    __shared__ cf tile[CT][CT + 1];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 x 4
+    const int r0 = blockIdx.y * CT, c0 = blockIdx.x * CT;
+#pragma unroll
+    for (int k = 0; k < CT; k += 4) {
+        const int r = r0 + ty + k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + k][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CT; k += 4) {
+        const int c = c0 + ty + k, r = r0 + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][ty + k];
+    }
+}
+hipError_t launch_corner_turn(const cf* in, cf* out, int rows, int cols, hipStream_t st) {
+    dim3 grid((cols + CT - 1) / CT, (rows + CT - 1) / CT);
+    hipLaunchKernelGGL(corner_turn_kernel, grid, dim3(256), 0, st, in, out, rows, cols);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------
+// multilook: out[R/L x C/L] = mean_{LxL} |in|^2.  One workgroup per output row
+// and 512-column chunk; reads are 16 B per lane along the contiguous dimension.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void multilook_kernel(const cf* __restrict__ in, float* __restrict__ out, int rows, int cols, int L) {
+    __shared__ float part[512];
+    const int orow = blockIdx.y;
+    const int c0 = blockIdx.x * 512 + threadIdx.x * 2;
+    float a0 = 0.f, a1 = 0.f;
+    if (c0 + 1 < cols) {
+        for (int l = 0; l < L; ++l) {
+            const float4 x = *reinterpret_cast<const float4*>(in + (size_t)(orow * L + l) * cols + c0);
+            a0 += x.x * x.x + x.y * x.y;
+            a1 += x.z * x.z + x.w * x.w;
+        }
+    }
+    part[threadIdx.x * 2] = a0;
+    part[threadIdx.x * 2 + 1] = a1;
+    __syncthreads();
+    const int nout = 512 / L;
+    const int ocols = cols / L;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int oc = blockIdx.x * nout + o;
+        if (oc < ocols) {
+            float s = 0.f;
+            for (int l = 0; l < L; ++l) s += part[o * L + l];
+            out[(size_t)orow * ocols + oc] = s / (float)(L * L);
+        }
+    }
+}
+hipError_t launch_multilook(const cf* in, float* out, int rows, int cols, int looks, hipStream_t st) {
+    dim3 grid((cols + 511) / 512, rows / looks);
+    hipLaunchKernelGGL(multilook_kernel, grid, dim3(256), 0, st, in, out, rows, cols, looks);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------
+// counter-based complex Gaussian noise: sample i depends only on (seed, i)
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void fill_noise_kernel(cf* buf, size_t n, uint64_t seed) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = mix64(seed * 0xD1342543DE82EF95ull + i);
+        const float u1 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);      // (0,1)
+        const float u2 = ((float)(uint32_t)((h >> 8) & 0xFFFFFF)) * (1.0f / 16777216.0f); // [0,1)
+        const float r = sqrtf(-2.0f * __logf(u1));
+        float s, c;
+        __sincosf(6.28318530718f * u2, &s, &c);
+        buf[i] = make_float2(r * c, r * s);
+    }
+}
+hipError_t launch_fill_noise(cf* buf, size_t n, uint64_t seed, hipStream_t st) {
+    size_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(fill_noise_kernel, dim3((unsigned)b), dim3(256), 0, st, buf, n, seed);
+    return hipGetLastError();
+}
+
+}  // namespace sarx

@@ -346,7 +346,7 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
     // measured on MI355X (profiles/): 32 pts/thread wins for one FFT per launch at n_rg >= 8192,
     // 16 pts/thread wins for the fused FFT+IFFT launch (the 32-pt form spills there)
     const bool v2 = range_v2_supported(p->n_rg) &&
-                    (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 16384 && mode != RG_FUSED));
+                    (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 8192 && mode != RG_FUSED));
     // impl 3: fused launch with wave-private sub-transforms; impl 4: persistent + register prefetch
     if (mode == RG_FUSED && range_fused_wl_supported(p->n_rg) && (c->range_impl == 3 || c->range_impl == 0))
         return launch_range_fused_wl(a, c->stream);

@@ -1,0 +1,166 @@
+/* sarx.h - C ABI of libsarx.so, the MI355X (gfx950) backend for the
+ * raw-echo -> Chirp-Scaling focus -> two-channel ATI/DPCA hot path of
+ * noiseinspacechannel/NIS-SAR-AMTIGMTI-Video.
+ *
+ * The reference has no FFI layer: its boundary is plain Python functions
+ * (SURVEY.md 8b).  Each entry point below names the reference code it
+ * replaces (file:line under the reference tree); INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; complex64 is two packed floats (re, im);
+ *  - every call returns 0 on success or a negative sarx_status; the message is
+ *    available from sarx_last_error(); nothing throws across the boundary;
+ *  - the caller owns every host buffer; device buffers come from sarx_malloc
+ *    (or are any valid HIP device pointer of this process) and are owned by
+ *    whoever allocated them; a plan owns its tables and scratch;
+ *  - one sarx_ctx per GPU; a ctx is not thread-safe; work is issued on the
+ *    ctx's own HIP stream; *_host calls and sarx_sync block, *_dev calls
+ *    only enqueue;
+ *  - there is no CPU fallback: without a usable gfx950 device sarx_init fails.
+ */
+#ifndef SARX_H
+#define SARX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SARX_VERSION 100
+
+typedef struct sarx_ctx sarx_ctx;
+typedef struct sarx_plan sarx_plan;
+
+typedef enum {
+    SARX_OK = 0,
+    SARX_ERR_INVALID = -1,      /* bad argument (size, null pointer, flag) */
+    SARX_ERR_UNSUPPORTED = -2,  /* size not a supported power of two, etc. */
+    SARX_ERR_DEVICE = -3,       /* HIP runtime error, text in sarx_last_error */
+    SARX_ERR_NOMEM = -4,
+    SARX_ERR_COMM = -5          /* RCCL error / not initialised */
+} sarx_status;
+
+/* Positional arguments of sar_focus_csa after `phist`
+ * (sar_ati_dcpa_sim_csa.py:202).  pulse_width_s is carried and unused, as in
+ * the reference. */
+typedef struct {
+    double wavelength_m;       /* center_wavelength_m  */
+    double pulse_width_s;      /* pulse_width_sec (unused by the algorithm) */
+    double chirp_rate_hz_s;    /* chirp_rate_hzpsec  Kr */
+    double sample_rate_hz;     /* sample_rate_hz     fs */
+    double prf_hz;             /* prf_hz */
+    double platform_speed_mps; /* platform_speed_mps Vr */
+    double range_ref_m;        /* range_ref_m        R_ref */
+    double t_start_fast_s;     /* t_start_fast */
+} sarx_radar_params;
+
+/* plan flags */
+#define SARX_OUT_AZ_MAJOR 0u      /* image left as [n_az x n_rg]; img.T is a view of it (what NumPy returns) */
+#define SARX_OUT_RG_MAJOR 1u      /* image corner-turned to row-major [n_rg x n_az] */
+#define SARX_FUSE_RANGE 2u        /* passes 2+3 (range FFT, Phi2, range IFFT, Phi3) in one launch */
+
+/* pass identifiers for sarx_csa_pass (per-pass parity tests and profiling) */
+#define SARX_PASS_AZ_FFT_PHI1 1   /* sar_ati_dcpa_sim_csa.py:233-274 */
+#define SARX_PASS_RG_FFT_PHI2 2   /* :278-326  (the roofline pass) */
+#define SARX_PASS_RG_IFFT_PHI3 3  /* :331-382 */
+#define SARX_PASS_AZ_IFFT 4       /* :385 */
+#define SARX_PASS_RG_FUSED_23 23  /* passes 2 and 3 in one launch */
+
+/* ---- context ------------------------------------------------------------- */
+int sarx_init(int device_id, sarx_ctx** out_ctx);
+int sarx_destroy(sarx_ctx* ctx);
+/* last error text of this ctx (or of the failed sarx_init when ctx is NULL) */
+const char* sarx_last_error(const sarx_ctx* ctx);
+int sarx_version(void);
+int sarx_device_count(int* out_count);
+int sarx_device_info(sarx_ctx* ctx, char* name, size_t name_len, int* compute_units,
+                     uint64_t* hbm_bytes, char* arch, size_t arch_len);
+
+/* ---- device memory and timing (so the Python host needs no torch) -------- */
+int sarx_malloc(sarx_ctx* ctx, size_t bytes, void** out_dptr);
+int sarx_free(sarx_ctx* ctx, void* dptr);
+int sarx_memcpy_h2d(sarx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int sarx_memcpy_d2h(sarx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int sarx_memcpy_d2d(sarx_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+int sarx_memset(sarx_ctx* ctx, void* dst_dev, int value, size_t bytes);
+int sarx_sync(sarx_ctx* ctx);
+/* HIP events on the ctx stream: record `slot` (0..255); elapsed ms between two recorded slots */
+int sarx_event_record(sarx_ctx* ctx, int slot);
+int sarx_event_elapsed_ms(sarx_ctx* ctx, int slot_start, int slot_stop, float* out_ms);
+
+/* ---- CSA focus: replaces sar_focus_csa (sar_ati_dcpa_sim_csa.py:202-396) -- */
+/* n_az, n_rg: powers of two, 16 <= n <= 16384 (non-power-of-two is a later row). */
+int sarx_csa_plan_create(sarx_ctx* ctx, int n_az, int n_rg, const sarx_radar_params* params,
+                         unsigned flags, sarx_plan** out_plan);
+int sarx_csa_plan_destroy(sarx_plan* plan);
+/* range_axis[n_rg] = c*tau/2 (:346,388); cross_range_axis[n_az] = (i/prf - mean)*Vr (:392-394) */
+int sarx_csa_axes(const sarx_plan* plan, double* range_axis, double* cross_range_axis);
+/* host in / host out, blocking: upload, four passes, download.
+ * phist: [n_az x n_rg] complex64 row-major.  image: n_az*n_rg complex64 in the plan's layout. */
+int sarx_csa_focus_host(sarx_plan* plan, const void* phist_host, void* image_host);
+/* device in / device out, asynchronous on the ctx stream.  d_phist is not modified.
+ * d_image must not alias d_phist. */
+int sarx_csa_focus_dev(sarx_plan* plan, const void* d_phist, void* d_image);
+/* one pass, device to device (d_out may equal d_in only for the range passes) */
+int sarx_csa_pass(sarx_plan* plan, int pass_id, const void* d_in, void* d_out);
+/* profiling hook: sarx_csa_focus_dev records ctx event slots around its range pass(es)
+ * (the roofline kernel); pass -1, -1 to switch off */
+int sarx_csa_plan_mark_range(sarx_plan* plan, int slot_start, int slot_stop);
+/* bytes of HBM scratch the plan holds (two ping-pong images + tables) */
+int sarx_csa_plan_bytes(const sarx_plan* plan, uint64_t* out_bytes);
+
+/* ---- ATI / DPCA: replaces the inline expressions of
+ *      sar_ati_dcpa_sim_csa.py:414-419,447-449 and
+ *      sar_ati_dcpa_viewer_csa.py:42-52,245-253 ------------------------------ */
+typedef struct {
+    /* required outputs, n floats each */
+    float* ati_phase;   /* angle(slc1 * conj(slc2_cal))   :414-415 */
+    float* slc1_mag;    /* |slc1|                          :416 */
+    float* dpca_mag;    /* |slc1 - slc2_cal|               :418-419 */
+    /* optional outputs (NULL = skip) */
+    void* ati_interf;   /* complex64 slc1*conj(slc2_cal)   :414 */
+    void* dpca_diff;    /* complex64 slc1 - slc2_cal       :418 */
+    float* slc2_mag;    /* viewer 'Ch2 Magnitude' */
+    float* slc1_phase;  /* viewer 'Ch1 Phase' */
+    float* slc2_phase;  /* viewer 'Ch2 Phase' */
+    float* dpca_phase;  /* viewer 'DPCA Phase' */
+} sarx_ati_outputs;      /* all device pointers */
+
+/* slc2_cal = slc2 * exp(i*cal_phase) (viewer :43).  Also reduces
+ * max|slc1| and sum(slc1*conj(slc2)) (uncalibrated: the phase-balance input,
+ * viewer :249).  Results land in host doubles after an internal sync. */
+int sarx_ati_dpca_dev(sarx_ctx* ctx, const void* d_slc1, const void* d_slc2, size_t n, double cal_phase,
+                      const sarx_ati_outputs* d_out, double* max_mag, double* sum_interf_re_im /*[2]*/);
+/* ati_phase[~(mag > thr)] = 0  (sar_ati_dcpa_sim_csa.py:447-449); d_out may alias d_phase */
+int sarx_mask_phase_dev(sarx_ctx* ctx, const float* d_phase, const float* d_mag, size_t n, float threshold,
+                        float* d_out);
+
+/* ---- corner turn (range <-> azimuth transpose through LDS tiles) --------- */
+/* out[c][r] = in[r][c], complex64, rows/cols multiples of 32 */
+int sarx_corner_turn_dev(sarx_ctx* ctx, const void* d_in, void* d_out, int rows, int cols);
+
+/* ---- VideoSAR stack products --------------------------------------------- */
+/* out[R/L x C/L] = mean over LxL blocks of |in|^2 (multilooked intensity), complex64 in, fp32 out */
+int sarx_multilook_dev(sarx_ctx* ctx, const void* d_in, float* d_out, int rows, int cols, int looks);
+
+/* ---- synthetic input on device ------------------------------------------- */
+/* counter-based N(0,1)+iN(0,1) complex64 noise, reproducible per (seed, index) */
+int sarx_fill_noise_c64(sarx_ctx* ctx, void* d_buf, size_t n, uint64_t seed);
+
+/* ---- multi-GPU: RCCL all-gather of the image stack over xGMI ------------- */
+#define SARX_COMM_ID_BYTES 128
+int sarx_comm_unique_id(void* id_out /*[SARX_COMM_ID_BYTES]*/);
+int sarx_comm_init(sarx_ctx* ctx, const void* id, int n_ranks, int rank);
+/* recv[rank r] = send of rank r; bytes_per_rank multiple of 4; async on the ctx comm stream,
+ * ordered after everything already enqueued on the compute stream */
+int sarx_allgather_dev(sarx_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+int sarx_comm_sync(sarx_ctx* ctx);
+int sarx_comm_destroy(sarx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SARX_H */
