@@ -82,13 +82,16 @@ def main():
 
     comm = d_slot = d_recv = None
     slot_bytes = (n // LOOKS) * (n // LOOKS) * 4
-    if world > 1:
+    force_comm = os.environ.get("SARX_BENCH_FORCE_COMM") == "1"     # exercise the gather path on one GPU
+    if world > 1 or force_comm:
         def bootstrap(uid):
+            if dist is None:
+                return uid
             box = [uid]
             dist.broadcast_object_list(box, src=0)
             return box[0]
         comm = RcclStackComm(ctx, world, rank, bootstrap)
-        d_slot = ctx.alloc(slot_bytes)
+        d_slot = ctx.alloc(slot_bytes * 2)                # double-buffered send slots
         d_recv = ctx.alloc(slot_bytes * world * 2)        # double-buffered round blocks
 
     def step(s, mark):
@@ -98,8 +101,10 @@ def main():
             plan.mark_range(-1, -1)
         plan.focus_dev(d_in, d_img)
         if comm is not None:
-            ctx.multilook(d_img, d_slot, n, n, LOOKS)
-            ctx.lib.sarx_allgather_dev(ctx.h, d_slot.ptr, d_recv.ptr + (s & 1) * slot_bytes * world, slot_bytes)
+            ctx.comm_fence_compute()                      # slot (s&1) was last read by the gather of step s-2
+            ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, d_slot.ptr + (s & 1) * slot_bytes, n, n, LOOKS)
+            ctx.lib.sarx_allgather_dev(ctx.h, d_slot.ptr + (s & 1) * slot_bytes,
+                                       d_recv.ptr + (s & 1) * slot_bytes * world, slot_bytes)
 
     def barrier():
         ctx.sync()

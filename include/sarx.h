@@ -150,6 +150,16 @@ int sarx_multilook_dev(sarx_ctx* ctx, const void* d_in, float* d_out, int rows, 
 /* counter-based N(0,1)+iN(0,1) complex64 noise, reproducible per (seed, index) */
 int sarx_fill_noise_c64(sarx_ctx* ctx, void* d_buf, size_t n, uint64_t seed);
 
+/* ---- point-target echo synthesis: the sample loops of run_physics_engine
+ *      (sar_satellite_sim.py:264-302) and run_bistatic_physics_gpu
+ *      (sar_ati_dcpa_sim_csa.py:137-178) ---------------------------------------
+ * raw[i][j] = sum_b amp[b] * [|u|<=Tp/2] * exp(2*pi*i*(pb[i][b] + 0.5*kr*u^2)),  u = t_fast[j]-tau[i][b]-Tp/2
+ * d_tau_pb: [n_pulses][n_targets] pairs of doubles {tau seconds, carrier phase in revolutions};
+ * d_amp: [n_targets] float sqrt(rcs); d_t_fast: [n_samples] double; d_raw: [n_pulses][n_samples] complex64 */
+int sarx_echo_synth_dev(sarx_ctx* ctx, const double* d_tau_pb, const float* d_amp, const double* d_t_fast,
+                        int n_pulses, int n_targets, int n_samples, double chirp_rate_hz_s, double pulse_width_s,
+                        void* d_raw);
+
 /* ---- multi-GPU: RCCL all-gather of the image stack over xGMI ------------- */
 #define SARX_COMM_ID_BYTES 128
 int sarx_comm_unique_id(void* id_out /*[SARX_COMM_ID_BYTES]*/);
@@ -158,6 +168,9 @@ int sarx_comm_init(sarx_ctx* ctx, const void* id, int n_ranks, int rank);
  * ordered after everything already enqueued on the compute stream */
 int sarx_allgather_dev(sarx_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 int sarx_comm_sync(sarx_ctx* ctx);
+/* device-side only: later work on the compute stream waits for every gather enqueued so far
+ * (call before overwriting a send buffer that an earlier sarx_allgather_dev may still read) */
+int sarx_comm_fence_compute(sarx_ctx* ctx);
 int sarx_comm_destroy(sarx_ctx* ctx);
 
 #ifdef __cplusplus

@@ -76,4 +76,15 @@ hipError_t launch_corner_turn(const float2* in, float2* out, int rows, int cols,
 hipError_t launch_multilook(const float2* in, float* out, int rows, int cols, int looks, hipStream_t st);
 hipError_t launch_fill_noise(float2* buf, size_t n, uint64_t seed, hipStream_t st);
 
+// echo.hip
+struct EchoArgs {
+    const double2* tau_pb;   // [n_pulses][n_targets] {delay s, carrier phase in revolutions}
+    const float* amp;        // [n_targets] sqrt(rcs)
+    const double* t_fast;    // [n_samples] absolute fast time of each sample
+    float2* out;             // [n_pulses][n_samples]
+    double kr, t_p;
+    int n_pulses, n_targets, n_samples;
+};
+hipError_t launch_echo_synth(const EchoArgs& a, hipStream_t st);
+
 }  // namespace sarx

@@ -56,6 +56,7 @@ struct sarx_ctx {
     hipEvent_t ev[N_EVENTS] = {};
     bool ev_set[N_EVENTS] = {};
     hipEvent_t comm_fence = nullptr;
+    hipEvent_t comm_done = nullptr;
     float2* tw_all = nullptr;          // table for size n at offset n: exp(-2 pi i m/n)
     float* ati_part_max = nullptr;     // reduction scratch
     double2* ati_part_sum = nullptr;
@@ -136,6 +137,7 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     for (int i = 0; i < N_EVENTS; ++i) HIPCHK(nullptr, hipEventCreate(&c->ev[i]));
     HIPCHK(nullptr, hipEventCreateWithFlags(&c->comm_fence, hipEventDisableTiming));
+    HIPCHK(nullptr, hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming));
     // twiddle tables for every power of two up to TW_MAX, fp64-evaluated
     std::vector<float2> tw(2 * TW_MAX);
     tw[0] = tw[1] = make_float2(1.f, 0.f);
@@ -161,6 +163,7 @@ int sarx_destroy(sarx_ctx* c) {
     hipFree(c->tw_all); hipFree(c->ati_part_max); hipFree(c->ati_part_sum); hipFree(c->ati_out3);
     for (int i = 0; i < N_EVENTS; ++i) hipEventDestroy(c->ev[i]);
     hipEventDestroy(c->comm_fence);
+    hipEventDestroy(c->comm_done);
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->comm_stream);
     delete c;
@@ -502,6 +505,19 @@ int sarx_multilook_dev(sarx_ctx* c, const void* in, float* out, int rows, int co
     return SARX_OK;
 }
 
+int sarx_echo_synth_dev(sarx_ctx* c, const double* tau_pb, const float* amp, const double* t_fast, int n_pulses,
+                        int n_targets, int n_samples, double kr, double t_p, void* raw) {
+    NEED_CTX(c);
+    if (!tau_pb || !amp || !t_fast || !raw) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (n_pulses <= 0 || n_targets <= 0 || n_samples <= 0 || n_pulses > 65535)
+        return fail(c, SARX_ERR_INVALID, "echo sizes must be positive (n_pulses <= 65535 per call)");
+    EchoArgs a{};
+    a.tau_pb = (const double2*)tau_pb; a.amp = amp; a.t_fast = t_fast; a.out = (float2*)raw;
+    a.kr = kr; a.t_p = t_p; a.n_pulses = n_pulses; a.n_targets = n_targets; a.n_samples = n_samples;
+    HIPCHK(c, launch_echo_synth(a, c->stream));
+    return SARX_OK;
+}
+
 int sarx_fill_noise_c64(sarx_ctx* c, void* buf, size_t n, uint64_t seed) {
     NEED_CTX(c);
     if (!buf) return fail(c, SARX_ERR_INVALID, "NULL pointer");
@@ -545,6 +561,12 @@ int sarx_allgather_dev(sarx_ctx* c, const void* send, void* recv, size_t bytes_p
     return SARX_OK;
 }
 int sarx_comm_sync(sarx_ctx* c) { NEED_CTX(c); HIPCHK(c, hipStreamSynchronize(c->comm_stream)); return SARX_OK; }
+int sarx_comm_fence_compute(sarx_ctx* c) {
+    NEED_CTX(c);
+    HIPCHK(c, hipEventRecord(c->comm_done, c->comm_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->comm_done, 0));
+    return SARX_OK;
+}
 int sarx_comm_destroy(sarx_ctx* c) {
     NEED_CTX(c);
     if (c->comm) { hipStreamSynchronize(c->comm_stream); g_rccl.CommDestroy(c->comm); c->comm = nullptr; }

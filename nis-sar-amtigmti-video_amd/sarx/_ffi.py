@@ -72,10 +72,12 @@ SIGNATURES = {
     "sarx_corner_turn_dev": (_i, [_vp, _vp, _vp, _i, _i]),
     "sarx_multilook_dev": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "sarx_fill_noise_c64": (_i, [_vp, _vp, _sz, _u64]),
+    "sarx_echo_synth_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _vp]),
     "sarx_comm_unique_id": (_i, [_vp]),
     "sarx_comm_init": (_i, [_vp, _vp, _i, _i]),
     "sarx_allgather_dev": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_comm_sync": (_i, [_vp]),
+    "sarx_comm_fence_compute": (_i, [_vp]),
     "sarx_comm_destroy": (_i, [_vp]),
 }
 

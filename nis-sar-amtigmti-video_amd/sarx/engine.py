@@ -108,6 +108,10 @@ class Context:
     def fill_noise(self, buf, n, seed):
         check(self.lib.sarx_fill_noise_c64(self.h, buf.ptr, int(n), int(seed)), self.h)
 
+    def echo_synth(self, d_tau_pb, d_amp, d_t_fast, n_pulses, n_targets, n_samples, kr, t_p, d_raw):
+        check(self.lib.sarx_echo_synth_dev(self.h, d_tau_pb.ptr, d_amp.ptr, d_t_fast.ptr, int(n_pulses), int(n_targets),
+                                           int(n_samples), float(kr), float(t_p), d_raw.ptr), self.h)
+
     def corner_turn(self, src, dst, rows, cols):
         check(self.lib.sarx_corner_turn_dev(self.h, src.ptr, dst.ptr, int(rows), int(cols)), self.h)
 
@@ -141,6 +145,10 @@ class Context:
 
     def allgather(self, send, recv, bytes_per_rank):
         check(self.lib.sarx_allgather_dev(self.h, send.ptr, recv.ptr, int(bytes_per_rank)), self.h)
+
+    def comm_fence_compute(self):
+        """Later compute-stream work waits (on the device) for every gather enqueued so far."""
+        check(self.lib.sarx_comm_fence_compute(self.h), self.h)
 
     def comm_sync(self):
         check(self.lib.sarx_comm_sync(self.h), self.h)

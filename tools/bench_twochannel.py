@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: two-channel n x n scene, CSA focus of both channels + ATI/DPCA on one MI355X.
+    python3 tools/bench_twochannel.py [size=8192] [frames=10]
+Echoes are device-resident noise; prints ms per frame, frames/s, and the ATI/DPCA kernel's GB/s
+against its 28 B/pixel algorithmic traffic."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nis-sar-amtigmti-video_amd"))
+import sarx  # noqa: E402
+from sarx import _ffi, radar  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+ctx = sarx.Context(0)
+plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE)
+px = n * n
+raw1, raw2, s1, s2 = (ctx.alloc(px * 8) for _ in range(4))
+outs = {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
+masked = ctx.alloc(px * 4)
+ctx.fill_noise(raw1, px, 1)
+ctx.fill_noise(raw2, px, 2)
+
+
+def frame():
+    plan.focus_dev(raw1, s1)
+    plan.focus_dev(raw2, s2)
+    ctx.record(10)
+    mx, _ = ctx.ati_dpca(s1, s2, px, 0.0, outs)          # syncs to return max|slc1| (mask threshold)
+    ctx.record(11)
+    ctx.mask_phase(outs["ati_phase"], outs["slc1_mag"], px, 0.05 * mx, masked)
+
+
+for _ in range(2):
+    frame()
+ctx.sync()
+ctx.record(0)
+ati_ms = 0.0
+for _ in range(frames):
+    frame()
+    ati_ms += ctx.elapsed_ms(10, 11)
+ctx.record(1)
+ms = ctx.elapsed_ms(0, 1) / frames
+ati_ms /= frames
+print(f"two-channel {n}x{n}: {ms:.3f} ms/frame = {1e3 / ms:.1f} frames/s (2 x CSA focus + ATI/DPCA + mask)")
+print(f"  ATI/DPCA launch + reduction: {ati_ms:.3f} ms -> {28.0 * px / ati_ms / 1e6:.1f} GB/s at 28 B/pixel")
