@@ -21,7 +21,6 @@ struct RangeArgs {
     double t0;            // 2 R_ref / c
     float inv_n;          // 1/n_rg
     int n_az;
-    int debug;            // ablation bits for timing experiments (SARX_DEBUG); 0 in production
 };
 
 struct AzArgs {
@@ -41,9 +40,6 @@ hipError_t launch_range_pass(int n_rg, int mode, const RangeArgs& a, hipStream_t
 // range_v2.hip: 32 points/thread, split re/im exchange (two lines resident per CU at 16384)
 bool range_v2_supported(int n_rg);
 hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
-// range_pf.hip: 16 points/thread, persistent workgroups that prefetch the next line into registers
-bool range_pf_supported(int n_rg);
-hipError_t launch_range_pass_pf(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
 // range_fused_wl.hip: fused FFT.Phi2.IFFT.Phi3 at 16384 with wave-private sub-transforms
 bool range_fused_wl_supported(int n_rg);
 hipError_t launch_range_fused_wl(const RangeArgs& a, hipStream_t st);

@@ -45,8 +45,7 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
 #pragma unroll
         for (int b = 0; b < P / R0; ++b)
 #pragma unroll
-            for (int r = 0; r < R0; ++r)
-                v[b * R0 + r] = (a.debug & 1) ? make_float2(t * 0.001f + r, b - t * 0.002f) : src[E::in_index(t, b, r)];
+            for (int r = 0; r < R0; ++r) v[b * R0 + r] = src[E::in_index(t, b, r)];
         stockham_run<N, 1, false, false>(v, t, 0, my_lds, a.tw);
         constexpr int RL = E::R_last;
         if constexpr (MODE == RG_FFT) {
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
                     const int reg = (m % B) * RL + m / B;
                     v[reg] = cmul(v[reg], q.next());
                     if constexpr (MODE == RG_FFT_PHI2) {
-                        if (live && (!(a.debug & 2) || v[reg].x == 1.2345e-30f)) dst[t + T * m] = v[reg];
+                        if (live) dst[t + T * m] = v[reg];
                     }
                 }
             }

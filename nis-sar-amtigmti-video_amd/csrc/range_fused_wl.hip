@@ -7,24 +7,20 @@
 //
 //   load   x[n1*1024 + n2]            thread t owns n2 = 2t, 2t+1 (16 B per lane), n1 = 0..15
 //   radix-16 over n1, twiddle W_N^(n2*q)                      -> y_q[n2], q = 0..15
-//   CROSS exchange (barriers): wave w takes the lines q = 2w, 2w+1
+//   CROSS exchange (2 barriers): wave w takes the lines q = 2w, 2w+1
 //   per wave: two 1024-point transforms over n2, 64 lanes x 16 points each, exchanged through
-//             a wave-private LDS region (no barriers: LDS ops of one wave execute in order),
-//             so the eight waves drift apart and overlap each other's LDS and VALU phases
+//             wave-private LDS regions (no barriers: LDS ops of one wave execute in order) and
+//             advanced stage by stage so one's LDS traffic flies while the other's butterflies issue
 //                                                              -> X[q + 16*k2]
 //   Phi_2 at bin k = q + 16*k2 (natural-order fftfreq value, any storage order)
 //   per wave: two inverse 1024-point transforms               -> z_q[n2]
-//   CROSS exchange back, twiddle conj(W_N^(n2*q)), inverse radix-16 over q
+//   CROSS exchange back (1 barrier), twiddle conj(W_N^(n2*q)), inverse radix-16 over q
 //   Phi_3 / N, store x[n1*1024 + n2]  (16 B per lane)
 //
-// Two residency forms (SARX_WL_SPLIT selects, default chosen by measurement):
-//   SPLIT = false: complex cross image [16][1088] cf = 136 KiB, one 512-thread workgroup per CU,
-//                  up to 256 VGPRs; the two sub-transforms of a wave run interleaved.
-//   SPLIT = true : the cross exchange moves real then imaginary parts through a float image
-//                  [16][1088] = 68 KiB, two workgroups per CU at <= 128 VGPRs, so one line's HBM
-//                  traffic overlaps the other's arithmetic; a wave's private region (its two rows
-//                  = one padded 1024-point complex image) serves its sub-transforms one at a time.
-// Workgroups are persistent (grid = resident workgroups), lines are walked with stride gridDim.x.
+// Residency: one persistent 512-thread workgroup per CU (complex cross image [16][1088] = 136 KiB),
+// two waves per SIMD, 141 VGPRs.  The register file, not LDS, rules out two lines per CU: the same
+// body capped at 128 VGPRs (real/imaginary parts exchanged separately through a 68 KiB image, two
+// workgroups per CU) spills 308 B/lane and runs 2.0 ms against 1.41 ms (measured).
 #include <cstdlib>
 #include "csa_kernels.h"
 #include "fft_core.hpp"
@@ -34,12 +30,9 @@ namespace sarx {
 
 namespace wl {
 constexpr int N = 16384, M = 1024, THREADS = 512;
-constexpr int ROWSTR = LdsSize<M, 1>::value;               // 1088: the padded 1024-point image
-template <bool SPLIT> constexpr size_t lds_bytes() { return (size_t)16 * ROWSTR * (SPLIT ? sizeof(float) : sizeof(cf)); }
+constexpr int ROWSTR = LdsSize<M, 1>::value;                     // 1088: the padded 1024-point image
+constexpr size_t LDS_BYTES = (size_t)16 * ROWSTR * sizeof(cf);   // 139264
 
-template <int C> __device__ __forceinline__ float& cm(cf& z) { if constexpr (C == 0) return z.x; else return z.y; }
-
-// ---- complex image ----
 // thread-major (v[b*16+q] = y_q[2t+b]) -> wave-major (v[s*16+r] = y_{2w+s}[l + 64 r])
 __device__ __forceinline__ void cross_fwd(cf* v, int t, int w, int l, cf* lds, bool lead_barrier) {
     if (lead_barrier) __syncthreads();
@@ -67,48 +60,22 @@ __device__ __forceinline__ void cross_inv(cf* v, int t, int w, int l, cf* lds) {
         v[16 + q] = make_float2(p.z, p.w);
     }
 }
-// ---- float image, one component per trip ----
-template <int C> __device__ __forceinline__ void cross_fwd_c(cf* v, int t, int w, int l, float* lds, bool lead_barrier) {
-    if (lead_barrier) __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-        *reinterpret_cast<float2*>(&lds[q * ROWSTR + 2 * t]) = make_float2(cm<C>(v[q]), cm<C>(v[16 + q]));
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cm<C>(v[s * 16 + r]) = lds[(2 * w + s) * ROWSTR + l + 64 * r];
-}
-template <int C> __device__ __forceinline__ void cross_inv_c(cf* v, int t, int w, int l, float* lds, bool lead_barrier) {
-    if (lead_barrier) __syncthreads();     // only the second component: others may still read my rows
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lds[(2 * w + s) * ROWSTR + l + 64 * r] = cm<C>(v[s * 16 + r]);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float2 p = *reinterpret_cast<const float2*>(&lds[q * ROWSTR + 2 * t]);
-        cm<C>(v[q]) = p.x;
-        cm<C>(v[16 + q]) = p.y;
-    }
-}
 }  // namespace wl
 
-template <bool SPLIT>
-__global__ __launch_bounds__(wl::THREADS, SPLIT ? 4 : 2) void range_fused_wl_kernel(RangeArgs a) {
+__global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArgs a) {
     using namespace wl;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
     const cf* __restrict__ tw = a.tw;                 // exp(-2 pi i m / 16384)
     const cf* __restrict__ tw_m = a.tw - N + M;       // the 1024 table sits at offset 1024 of the same array
 
     for (int row = blockIdx.x; row < a.n_az; row += gridDim.x) {
         int t = threadIdx.x;
-        asm volatile("" : "+v"(t));                   // keep addresses per-line (no hoisting out of the loop)
+        asm volatile("" : "+v"(t));                   // keep addresses per-line (no hoisting out of the loop + spilling)
         const int w = t >> 6, l = t & 63;
-        const bool not_first = row != (int)blockIdx.x;
         const cf* __restrict__ src = a.in + (size_t)row * N;
         cf* __restrict__ dst = a.out + (size_t)row * N;
+        cf* priv0 = lds + (2 * w) * ROWSTR;           // wave-private: lines 2w and 2w+1 of the cross image
 
         cf v[32];
 #pragma unroll
@@ -123,21 +90,8 @@ __global__ __launch_bounds__(wl::THREADS, SPLIT ? 4 : 2) void range_fused_wl_ker
             dft16<false>(v + 16 * b);
             apply_twiddle_powers<16>(v + 16 * b, stage_twiddle<N, N, false>(2 * t + b, tw));
         }
-        if constexpr (SPLIT) {
-            float* lds = reinterpret_cast<float*>(smem_raw);
-            cf* priv = reinterpret_cast<cf*>(lds + 2 * w * ROWSTR);   // rows 2w, 2w+1 = 1088 cf
-            cross_fwd_c<0>(v, t, w, l, lds, not_first);
-            cross_fwd_c<1>(v, t, w, l, lds, true);
-            exchange_sync<true>();
-            stockham_run<M, 1, false, false, 0, true>(v, l, 0, priv, tw_m);
-            exchange_sync<true>();
-            stockham_run<M, 1, false, false, 0, true>(v + 16, l, 0, priv, tw_m);
-        } else {
-            cf* lds = reinterpret_cast<cf*>(smem_raw);
-            cf* priv0 = lds + (2 * w) * ROWSTR;       // wave-private: lines 2w and 2w+1 of the cross image
-            cross_fwd(v, t, w, l, lds, not_first);
-            stockham_run2_wave<M, false, false>(v, v + 16, l, priv0, priv0 + ROWSTR, tw_m);
-        }
+        cross_fwd(v, t, w, l, lds, row != (int)blockIdx.x);
+        stockham_run2_wave<M, false, false>(v, v + 16, l, priv0, priv0 + ROWSTR, tw_m);
         // Phi_2: register (s; b, r) of the radix-4 last stage holds k2 = l + 64 m, m = b + 4 r, i.e. bin
         // k = (2w+s) + 16 l + 1024 m; m >= 8 are the negative frequencies
         {
@@ -156,23 +110,9 @@ __global__ __launch_bounds__(wl::THREADS, SPLIT ? 4 : 2) void range_fused_wl_ker
             }
         }
         // two wave-private inverse transforms; the reversed plan starts on the radix-4 layout just produced
-        if constexpr (SPLIT) {
-            float* lds = reinterpret_cast<float*>(smem_raw);
-            cf* priv = reinterpret_cast<cf*>(lds + 2 * w * ROWSTR);
-            exchange_sync<true>();
-            stockham_run<M, 1, true, true, 0, true>(v, l, 0, priv, tw_m);
-            exchange_sync<true>();
-            stockham_run<M, 1, true, true, 0, true>(v + 16, l, 0, priv, tw_m);
-            exchange_sync<true>();
-            cross_inv_c<0>(v, t, w, l, lds, false);
-            cross_inv_c<1>(v, t, w, l, lds, true);
-        } else {
-            cf* lds = reinterpret_cast<cf*>(smem_raw);
-            cf* priv0 = lds + (2 * w) * ROWSTR;
-            stockham_run2_wave<M, true, true>(v, v + 16, l, priv0, priv0 + ROWSTR, tw_m);
-            exchange_sync<true>();
-            cross_inv(v, t, w, l, lds);
-        }
+        stockham_run2_wave<M, true, true>(v, v + 16, l, priv0, priv0 + ROWSTR, tw_m);
+        exchange_sync<true>();
+        cross_inv(v, t, w, l, lds);
         // conj twiddle, inverse radix-16 over q
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -196,39 +136,25 @@ __global__ __launch_bounds__(wl::THREADS, SPLIT ? 4 : 2) void range_fused_wl_ker
     }
 }
 
-static int wl_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
 bool range_fused_wl_supported(int n_rg) { return n_rg == wl::N; }
 
-template <bool SPLIT> static hipError_t launch_wl(const RangeArgs& a, hipStream_t st) {
+hipError_t launch_range_fused_wl(const RangeArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto k = range_fused_wl_kernel<SPLIT>;
+    static int cus = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)wl::lds_bytes<SPLIT>());
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_fused_wl_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl::LDS_BYTES);
         if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
         attr_set = true;
     }
-    int grid = (SPLIT ? 2 : 1) * wl_num_cus();          // resident workgroups, persistent over lines
-    if (const char* e = getenv("SARX_WL_WGS_PER_CU")) { const int w = atoi(e); grid = (w <= 0) ? a.n_az : w * wl_num_cus(); }
+    int grid = cus;                                    // one resident workgroup per CU, persistent over lines
     if (grid > a.n_az) grid = a.n_az;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(wl::THREADS), wl::lds_bytes<SPLIT>(), st, a);
+    hipLaunchKernelGGL(range_fused_wl_kernel, dim3(grid), dim3(wl::THREADS), wl::LDS_BYTES, st, a);
     return hipGetLastError();
-}
-
-hipError_t launch_range_fused_wl(const RangeArgs& a, hipStream_t st) {
-    static int split = -1;
-    if (split < 0) { const char* e = getenv("SARX_WL_SPLIT"); split = e ? atoi(e) : 0; }
-    return split ? launch_wl<true>(a, st) : launch_wl<false>(a, st);
 }
 
 }  // namespace sarx

@@ -63,7 +63,7 @@ struct sarx_ctx {
     double* ati_out3 = nullptr;
     ncclComm_t comm = nullptr;
     int n_ranks = 0, rank = 0;
-    int range_impl = 0;                // 0 auto, 1 = 16 pts/thread, 2 = 32 pts/thread split exchange (SARX_RANGE_IMPL)
+    int range_impl = 0;                // SARX_RANGE_IMPL: 0 auto, 1 = 16 pts/thread, 2 = 32 pts/thread split exchange, 3 = fused wave-private
     std::string err;
 };
 
@@ -340,7 +340,6 @@ static RangeArgs range_args(const sarx_plan* p, const void* in, void* out) {
     a.t0 = 2.0 * p->p.range_ref_m / C_LIGHT;
     a.inv_n = 1.0f / (float)p->n_rg;
     a.n_az = p->n_az;
-    if (const char* e = getenv("SARX_DEBUG")) a.debug = atoi(e);
     return a;
 }
 
@@ -350,10 +349,9 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
     // 16 pts/thread wins for the fused FFT+IFFT launch (the 32-pt form spills there)
     const bool v2 = range_v2_supported(p->n_rg) &&
                     (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 16384 && mode != RG_FUSED));
-    // impl 3: fused launch with wave-private sub-transforms; impl 4: persistent + register prefetch
+    // impl 3 (default for the fused launch at 16384): wave-private sub-transforms
     if (mode == RG_FUSED && range_fused_wl_supported(p->n_rg) && (c->range_impl == 3 || c->range_impl == 0))
         return launch_range_fused_wl(a, c->stream);
-    if (range_pf_supported(p->n_rg) && c->range_impl == 4) return launch_range_pass_pf(p->n_rg, mode, a, c->stream);
     return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
 }
 

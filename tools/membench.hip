@@ -12,6 +12,35 @@ __global__ __launch_bounds__(256) void flat_copy(const float4* __restrict__ in, 
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) out[i] = in[i];
 }
+typedef float v4f __attribute__((ext_vector_type(4)));
+// NT: 1 = nontemporal loads, 2 = nontemporal stores, 3 = both
+template <int NT> __global__ __launch_bounds__(256) void flat_copy_nt(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const v4f* pi = reinterpret_cast<const v4f*>(&in[i]);
+        v4f* po = reinterpret_cast<v4f*>(&out[i]);
+        v4f v = (NT & 1) ? __builtin_nontemporal_load(pi) : *pi;
+        if (NT & 2) __builtin_nontemporal_store(v, po); else *po = v;
+    }
+}
+template <int T, int PTS, int NT>
+__global__ __launch_bounds__(T) void line_copy_nt(const float2* __restrict__ in, float2* __restrict__ out, int n) {
+    extern __shared__ char smem[];
+    const size_t row = blockIdx.x;
+    const int t = threadIdx.x;
+    v4f v[PTS / 2];
+#pragma unroll
+    for (int i = 0; i < PTS / 2; ++i) {
+        const v4f* p = reinterpret_cast<const v4f*>(&in[row * n + 2 * t + i * 2 * T]);
+        v[i] = (NT & 1) ? __builtin_nontemporal_load(p) : *p;
+    }
+    if (n < 0) smem[t] = 1;
+#pragma unroll
+    for (int i = 0; i < PTS / 2; ++i) {
+        v4f* p = reinterpret_cast<v4f*>(&out[row * n + 2 * t + i * 2 * T]);
+        if (NT & 2) __builtin_nontemporal_store(v[i], p); else *p = v[i];
+    }
+}
 
 // tile: 128 rows x W cols of float2; VEC = float2 per lane per access (1 -> 8 B, 2 -> 16 B)
 // thread (c, t), t in [0,8): rows m = t + 8*i, i < 16.
@@ -88,6 +117,18 @@ int main() {
         rep(blocks == 2048 ? "flat copy float4 grid 2048" : blocks == 8192 ? "flat copy float4 grid 8192" : "flat copy float4 grid 65536",
             time_ms([&] { hipLaunchKernelGGL(flat_copy, dim3(blocks), dim3(256), 0, 0, (const float4*)in, (float4*)out, elems / 2); }));
 
+    rep("flat copy nt loads  grid 65536", time_ms([&] { hipLaunchKernelGGL((flat_copy_nt<1>), dim3(65536), dim3(256), 0, 0, (const float4*)in, (float4*)out, elems / 2); }));
+    rep("flat copy nt stores grid 65536", time_ms([&] { hipLaunchKernelGGL((flat_copy_nt<2>), dim3(65536), dim3(256), 0, 0, (const float4*)in, (float4*)out, elems / 2); }));
+    rep("flat copy nt both   grid 65536", time_ms([&] { hipLaunchKernelGGL((flat_copy_nt<3>), dim3(65536), dim3(256), 0, 0, (const float4*)in, (float4*)out, elems / 2); }));
+    rep("flat copy nt both   grid 2048", time_ms([&] { hipLaunchKernelGGL((flat_copy_nt<3>), dim3(2048), dim3(256), 0, 0, (const float4*)in, (float4*)out, elems / 2); }));
+    CK(hipFuncSetAttribute((const void*)line_copy_nt<512, 32, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 69632));
+    CK(hipFuncSetAttribute((const void*)line_copy_nt<512, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 69632));
+    CK(hipFuncSetAttribute((const void*)line_copy_nt<512, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 69632));
+    CK(hipFuncSetAttribute((const void*)line_copy_nt<512, 32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 69632));
+    rep("line copy 512thr 2/CU plain", time_ms([&] { hipLaunchKernelGGL((line_copy_nt<512, 32, 0>), dim3(n), dim3(512), 69632, 0, in, out, n); }));
+    rep("line copy 512thr 2/CU nt loads", time_ms([&] { hipLaunchKernelGGL((line_copy_nt<512, 32, 1>), dim3(n), dim3(512), 69632, 0, in, out, n); }));
+    rep("line copy 512thr 2/CU nt stores", time_ms([&] { hipLaunchKernelGGL((line_copy_nt<512, 32, 2>), dim3(n), dim3(512), 69632, 0, in, out, n); }));
+    rep("line copy 512thr 2/CU nt both", time_ms([&] { hipLaunchKernelGGL((line_copy_nt<512, 32, 3>), dim3(n), dim3(512), 69632, 0, in, out, n); }));
     const int S = 128, RA = 128;
     // step A: rows q + m*S in place (q < S)
     rep("az step A  W=32  8B/lane", time_ms([&] { hipLaunchKernelGGL((tile_copy<32, 1>), dim3(n / 32, S), dim3(256), 0, 0, in, out, n, 1, S, 1, S); }));
