@@ -208,9 +208,16 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             const size_t rowo = out_base + (size_t)m * a.out_m_stride;
             cf x = v[b * RL + r];
             if constexpr (EPI == AZ_EPI_TWIDDLE) {
-                cf w = a.tw_n[(size_t)q * m];          // q*m < n_az
+                // four-step twiddle W_n^(q*m): q*m < n_az <= 2^14 and 1/n_az is a power of two, so the
+                // argument is exact in fp32 (HW sine/cosine take revolutions; no table load in this pass)
+#if SARX_HW_TWIDDLE
+                const float rev = (float)(q * m) * a.scale;
+                x = cmul(x, cis_frac(INV ? rev : -rev));
+#else
+                cf w = a.tw_n[(size_t)q * m];
                 if (INV) w = cconj(w);
                 x = cmul(x, w);
+#endif
             } else if constexpr (EPI == AZ_EPI_PHI1) {
                 x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
             } else if constexpr (EPI == AZ_EPI_SCALE) {
