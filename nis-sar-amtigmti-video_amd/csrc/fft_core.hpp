@@ -90,6 +90,44 @@ template <bool INV> __device__ __forceinline__ void dft16(cf* v) {
         v[k2] = a; v[4 + k2] = b; v[8 + k2] = c; v[12 + k2] = d;
     }
 }
+// 32 points: two 16-point DFTs of the even and odd samples, then X[k] = E[k] +- W32^k O[k]
+template <bool INV> __device__ __forceinline__ void dft32(cf* v) {
+    cf e[16], o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    dft16<INV>(e);
+    dft16<INV>(o);
+    // cos, sin of pi*k/16, k = 0..15
+    constexpr float C32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                               0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                               0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
+                               -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                               -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float S32[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                               0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                               0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
+                               0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                               0.38268343236508977173f, 0.19509032201612826785f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf t;
+        if (k == 0) t = o[0];
+        else if (k == 8) t = mul_mi<INV>(o[8]);
+        else t = cmul(o[k], make_float2(C32[k], INV ? S32[k] : -S32[k]));
+        v[k] = cadd(e[k], t);
+        v[k + 16] = csub(e[k], t);
+    }
+}
+// v[r] *= w^r, r = 1..31; w^r = w^(r/2) * w^(r - r/2): depth 5
+__device__ __forceinline__ void apply_twiddle_powers32(cf* v, cf w1) {
+    cf w[32];
+    w[1] = w1;
+#pragma unroll
+    for (int r = 2; r < 32; ++r) w[r] = cmul(w[r / 2], w[r - r / 2]);
+#pragma unroll
+    for (int r = 1; r < 32; ++r) v[r] = cmul(v[r], w[r]);
+}
+
 template <int R, bool INV> __device__ __forceinline__ void dft(cf* v) {
     if constexpr (R == 2) dft2<INV>(v[0], v[1]);
     else if constexpr (R == 4) dft4<INV>(v[0], v[1], v[2], v[3]);
@@ -249,31 +287,6 @@ __device__ __forceinline__ void stockham_run(cf* v, int t, int c, cf* lds, const
         exchange_sync<WAVE_LOCAL>();
         stage_gather<N, PL::T, R2, W>(v, t, c, lds);
         stockham_run<N, W, INV, REV, S + 1, WAVE_LOCAL>(v, t, c, lds, tw);
-    }
-}
-
-// Two independent wave-local transforms A and B advanced stage by stage, ordered so that one's
-// LDS traffic is in flight while the other's butterflies issue (the only LDS/VALU overlap a
-// wave can get on its own): compute A, scatter A, compute B, scatter B, gather A, gather B.
-template <int N, bool INV, bool REV, int S = 0>
-__device__ __forceinline__ void stockham_run2_wave(cf* va, cf* vb, int t, cf* la, cf* lb, const cf* __restrict__ tw) {
-    using PL = Plan<N>;
-    static_assert(PL::T == 64, "wave-local transforms span exactly one wavefront");
-    constexpr int R = PL::template radix<REV>(S);
-    constexpr int NS = PL::template ns_before<REV>(S);
-    stage_compute<N, PL::T, R, NS, INV>(va, t, tw);
-    if constexpr (S + 1 < PL::nstages) {
-        constexpr int R2 = PL::template radix<REV>(S + 1);
-        exchange_sync<true>();
-        stage_scatter<N, PL::T, R, NS, 1>(va, t, 0, la);
-        stage_compute<N, PL::T, R, NS, INV>(vb, t, tw);
-        stage_scatter<N, PL::T, R, NS, 1>(vb, t, 0, lb);
-        exchange_sync<true>();
-        stage_gather<N, PL::T, R2, 1>(va, t, 0, la);
-        stage_gather<N, PL::T, R2, 1>(vb, t, 0, lb);
-        stockham_run2_wave<N, INV, REV, S + 1>(va, vb, t, la, lb, tw);
-    } else {
-        stage_compute<N, PL::T, R, NS, INV>(vb, t, tw);
     }
 }
 

@@ -8,9 +8,8 @@
 //   load   x[n1*1024 + n2]            thread t owns n2 = 2t, 2t+1 (16 B per lane), n1 = 0..15
 //   radix-16 over n1, twiddle W_N^(n2*q)                      -> y_q[n2], q = 0..15
 //   CROSS exchange (2 barriers): wave w takes the lines q = 2w, 2w+1
-//   per wave: two 1024-point transforms over n2, 64 lanes x 16 points each, exchanged through
-//             wave-private LDS regions (no barriers: LDS ops of one wave execute in order) and
-//             advanced stage by stage so one's LDS traffic flies while the other's butterflies issue
+//   per half wave: one 1024-point transform over n2 as 32 x 32 (32 lanes x 32 points), its single
+//             exchange through a private LDS region (no barriers: LDS ops of one wave execute in order)
 //                                                              -> X[q + 16*k2]
 //   Phi_2 at bin k = q + 16*k2 (natural-order fftfreq value, any storage order)
 //   per wave: two inverse 1024-point transforms               -> z_q[n2]
@@ -18,9 +17,9 @@
 //   Phi_3 / N, store x[n1*1024 + n2]  (16 B per lane)
 //
 // Residency: one persistent 512-thread workgroup per CU (complex cross image [16][1088] = 136 KiB),
-// two waves per SIMD, 141 VGPRs.  The register file, not LDS, rules out two lines per CU: the same
+// two waves per SIMD, 164 VGPRs.  The register file, not LDS, rules out two lines per CU: the same
 // body capped at 128 VGPRs (real/imaginary parts exchanged separately through a 68 KiB image, two
-// workgroups per CU) spills 308 B/lane and runs 2.0 ms against 1.41 ms (measured).
+// workgroups per CU) spills 308 B/lane and runs 2.0 ms against 1.4 ms (measured).
 #include <cstdlib>
 #include "csa_kernels.h"
 #include "fft_core.hpp"
@@ -33,25 +32,25 @@ constexpr int N = 16384, M = 1024, THREADS = 512;
 constexpr int ROWSTR = LdsSize<M, 1>::value;                     // 1088: the padded 1024-point image
 constexpr size_t LDS_BYTES = (size_t)16 * ROWSTR * sizeof(cf);   // 139264
 
-// thread-major (v[b*16+q] = y_q[2t+b]) -> wave-major (v[s*16+r] = y_{2w+s}[l + 64 r])
-__device__ __forceinline__ void cross_fwd(cf* v, int t, int w, int l, cf* lds, bool lead_barrier) {
+// Wave-private 1024-point transforms as 32 x 32: half-wave h = l >> 5 owns line 2w+h, lane i = l & 31
+// holds its points i + 32 r, r = 0..31.  One LDS exchange per transform (radix-32 twice); the 16.16.4
+// form with two exchanges measured 4 % slower (1.345 vs 1.29 ms).
+__device__ __forceinline__ int pad32(int idx) { return idx + (idx >> 5); }   // stride-32 writes hit distinct banks
+
+__device__ __forceinline__ void cross_fwd32(cf* v, int t, int w, int l, cf* lds, bool lead_barrier) {
     if (lead_barrier) __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; ++q)
         *reinterpret_cast<float4*>(&lds[q * ROWSTR + 2 * t]) = make_float4(v[q].x, v[q].y, v[16 + q].x, v[16 + q].y);
     __syncthreads();
+    const cf* line = lds + (2 * w + (l >> 5)) * ROWSTR + (l & 31);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[s * 16 + r] = lds[(2 * w + s) * ROWSTR + l + 64 * r];
+    for (int r = 0; r < 32; ++r) v[r] = line[32 * r];
 }
-// wave-major -> thread-major.  Each wave writes only its own two lines, which nobody else has read
-// since the forward cross exchange, so no leading barrier.
-__device__ __forceinline__ void cross_inv(cf* v, int t, int w, int l, cf* lds) {
+__device__ __forceinline__ void cross_inv32(cf* v, int t, int w, int l, cf* lds) {
+    cf* line = lds + (2 * w + (l >> 5)) * ROWSTR + (l & 31);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lds[(2 * w + s) * ROWSTR + l + 64 * r] = v[s * 16 + r];
+    for (int r = 0; r < 32; ++r) line[32 * r] = v[r];
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -59,6 +58,22 @@ __device__ __forceinline__ void cross_inv(cf* v, int t, int w, int l, cf* lds) {
         v[q] = make_float2(p.x, p.y);
         v[16 + q] = make_float2(p.z, p.w);
     }
+}
+// one 1024-point transform of the half wave, in place in v: inputs v[r] = x[i + 32 r], outputs v[r] = X[i + 32 r]
+// wp[r] = W_1024^(i r) depends on the lane only: computed once per kernel, kept in registers (62 VGPRs)
+template <bool INV> __device__ __forceinline__ void sub1024_r32(cf* v, int i, cf* img, const cf* wp) {
+    dft32<INV>(v);
+    exchange_sync<true>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) img[pad32(32 * i + r)] = v[r];
+    exchange_sync<true>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r] = img[pad32(i + 32 * r)];
+#pragma unroll
+    for (int r = 1; r < 32; ++r)
+        v[r] = INV ? make_float2(fmaf(v[r].x, wp[r].x, v[r].y * wp[r].y), fmaf(v[r].y, wp[r].x, -v[r].x * wp[r].y))   // * conj
+                   : cmul(v[r], wp[r]);
+    dft32<INV>(v);
 }
 }  // namespace wl
 
@@ -69,13 +84,30 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
     const cf* __restrict__ tw = a.tw;                 // exp(-2 pi i m / 16384)
     const cf* __restrict__ tw_m = a.tw - N + M;       // the 1024 table sits at offset 1024 of the same array
 
+    cf wp[32];
+    {
+        const cf w1 = stage_twiddle<M, M, false>((int)(threadIdx.x & 31), tw_m);
+        wp[0] = make_float2(1.f, 0.f);
+        wp[1] = w1;
+#pragma unroll
+        for (int r = 2; r < 32; ++r) wp[r] = cmul(wp[r / 2], wp[r - r / 2]);
+    }
+    // cross twiddles W_N^((2t+b) q), q = 1..15: thread constants as well (60 VGPRs)
+    cf cw[2][16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const cf w1 = stage_twiddle<N, N, false>(2 * (int)threadIdx.x + b, tw);
+        cw[b][0] = make_float2(1.f, 0.f);
+        cw[b][1] = w1;
+#pragma unroll
+        for (int q = 2; q < 16; ++q) cw[b][q] = cmul(cw[b][q / 2], cw[b][q - q / 2]);
+    }
     for (int row = blockIdx.x; row < a.n_az; row += gridDim.x) {
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));                   // keep addresses per-line (no hoisting out of the loop + spilling)
         const int w = t >> 6, l = t & 63;
         const cf* __restrict__ src = a.in + (size_t)row * N;
         cf* __restrict__ dst = a.out + (size_t)row * N;
-        cf* priv0 = lds + (2 * w) * ROWSTR;           // wave-private: lines 2w and 2w+1 of the cross image
 
         cf v[32];
 #pragma unroll
@@ -88,35 +120,34 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             dft16<false>(v + 16 * b);
-            apply_twiddle_powers<16>(v + 16 * b, stage_twiddle<N, N, false>(2 * t + b, tw));
+#pragma unroll
+            for (int q = 1; q < 16; ++q) v[16 * b + q] = cmul(v[16 * b + q], cw[b][q]);
         }
-        cross_fwd(v, t, w, l, lds, row != (int)blockIdx.x);
-        stockham_run2_wave<M, false, false>(v, v + 16, l, priv0, priv0 + ROWSTR, tw_m);
-        // Phi_2: register (s; b, r) of the radix-4 last stage holds k2 = l + 64 m, m = b + 4 r, i.e. bin
-        // k = (2w+s) + 16 l + 1024 m; m >= 8 are the negative frequencies
+        cf* img = lds + (2 * w + (l >> 5)) * ROWSTR;  // the half wave's private image
+        const int li = l & 31;
+        cross_fwd32(v, t, w, l, lds, row != (int)blockIdx.x);
+        sub1024_r32<false>(v, li, img, wp);
+        // Phi_2: v[r] is bin k = (2w+h) + 16 i + 512 r; r >= 16 are the negative frequencies
         {
             const double2 c2 = a.c2[row];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const int ks = 2 * w + 16 * l + half * (8 * 1024 - N);     // signed fftfreq index at m = 8*half
-                FixPhase q0 = phi2_seed(ks, 1024, c2, a.df), q1 = phi2_seed(ks + 1, 1024, c2, a.df);
+                FixPhase q0 = phi2_seed(2 * w + (l >> 5) + 16 * li + half * (8192 - N), 512, c2, a.df);
 #pragma unroll
-                for (int mm = 0; mm < 8; ++mm) {
-                    const int m = half * 8 + mm;
-                    const int reg = (m % 4) * 4 + m / 4;
-                    v[reg] = cmul(v[reg], q0.next());
-                    v[16 + reg] = cmul(v[16 + reg], q1.next());
-                }
+                for (int rr = 0; rr < 16; ++rr) v[half * 16 + rr] = cmul(v[half * 16 + rr], q0.next());
             }
         }
-        // two wave-private inverse transforms; the reversed plan starts on the radix-4 layout just produced
-        stockham_run2_wave<M, true, true>(v, v + 16, l, priv0, priv0 + ROWSTR, tw_m);
+        sub1024_r32<true>(v, li, img, wp);
         exchange_sync<true>();
-        cross_inv(v, t, w, l, lds);
+        cross_inv32(v, t, w, l, lds);
         // conj twiddle, inverse radix-16 over q
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            apply_twiddle_powers<16>(v + 16 * b, stage_twiddle<N, N, true>(2 * t + b, tw));
+#pragma unroll
+            for (int q = 1; q < 16; ++q) {       // * conj(cw)
+                const cf x = v[16 * b + q], c = cw[b][q];
+                v[16 * b + q] = make_float2(fmaf(x.x, c.x, x.y * c.y), fmaf(x.y, c.x, -x.x * c.y));
+            }
             dft16<true>(v + 16 * b);
         }
         // Phi_3 / N and store: v[b*16 + n1] = N * x[n1*1024 + 2t + b]
