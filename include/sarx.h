@@ -92,7 +92,9 @@ int sarx_event_record(sarx_ctx* ctx, int slot);
 int sarx_event_elapsed_ms(sarx_ctx* ctx, int slot_start, int slot_stop, float* out_ms);
 
 /* ---- CSA focus: replaces sar_focus_csa (sar_ati_dcpa_sim_csa.py:202-396) -- */
-/* n_az, n_rg: powers of two, 16 <= n <= 16384 (non-power-of-two is a later row). */
+/* n_az, n_rg in [2, 16384].  Powers of two >= 16 run the tuned kernels; any other size (the
+ * reference's native 7199 x 13200, :47,111,402) runs chirp-z transforms over them (a non-power-of-two
+ * n_az must be <= 8192).  Unsupported sizes fail with SARX_ERR_UNSUPPORTED, never silently. */
 int sarx_csa_plan_create(sarx_ctx* ctx, int n_az, int n_rg, const sarx_radar_params* params,
                          unsigned flags, sarx_plan** out_plan);
 int sarx_csa_plan_destroy(sarx_plan* plan);

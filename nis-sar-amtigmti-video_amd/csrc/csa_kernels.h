@@ -7,7 +7,9 @@
 namespace sarx {
 
 enum RangeMode { RG_FFT = 0, RG_IFFT = 1, RG_FFT_PHI2 = 2, RG_IFFT_PHI3 = 3, RG_FUSED = 4 };
-enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_SCALE = 3 };
+enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_SCALE = 3,
+                  AZ_EPI_TWCOL = 4,      // * W_M^(col*m_out), M = 1/tw_scale (32768-point line split, forward)
+                  AZ_EPI_PROCOL = 5 };   // inputs * W_M^(col*m_in) first, outputs * scale (its inverse)
 
 struct RangeArgs {
     const float2* in;
@@ -31,6 +33,7 @@ struct AzArgs {
     const double2* c1;    // per azimuth bin: {-0.5 Kr Cs, tau_ref}
     double dt, t_start;
     float scale;          // 1/n_az for the inverse's last step
+    float tw_scale;       // 1/M for the column-indexed twiddles of the 32768-point line split
     int n_rg;
     // row of tile element m for tile q: q*q_stride + m*m_stride
     int in_q_stride, in_m_stride, out_q_stride, out_m_stride;

@@ -195,8 +195,14 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
     for (int b = 0; b < P / R0; ++b)
 #pragma unroll
         for (int r = 0; r < R0; ++r) {
-            const size_t rowi = in_base + (size_t)E::in_index(t, b, r) * a.in_m_stride;
-            v[b * R0 + r] = a.in[rowi * a.n_rg + col];
+            const int mi = E::in_index(t, b, r);
+            const size_t rowi = in_base + (size_t)mi * a.in_m_stride;
+            cf x = a.in[rowi * a.n_rg + col];
+            if constexpr (EPI == AZ_EPI_PROCOL) {      // inverse of the 32768-point line split: W_M^(+-col*m_in) first
+                const float rev = (float)(col * mi) * a.tw_scale;
+                x = cmul(x, cis_frac(INV ? rev : -rev));
+            }
+            v[b * R0 + r] = x;
         }
     stockham_run<R, W, INV, false>(v, t, c, lds, a.tw_r);
     constexpr int RL = E::R_last;
@@ -220,8 +226,11 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
 #endif
             } else if constexpr (EPI == AZ_EPI_PHI1) {
                 x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
-            } else if constexpr (EPI == AZ_EPI_SCALE) {
+            } else if constexpr (EPI == AZ_EPI_SCALE || EPI == AZ_EPI_PROCOL) {
                 x.x *= a.scale; x.y *= a.scale;
+            } else if constexpr (EPI == AZ_EPI_TWCOL) {    // 32768-point line as 128 x 256: twiddle W_M^(+-col*m)
+                const float rev = (float)(col * m) * a.tw_scale;
+                x = cmul(x, cis_frac(INV ? rev : -rev));
             }
             a.out[rowo * a.n_rg + col] = x;
         }
@@ -239,12 +248,14 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_NONE: return launch_az_one<R, W, false, AZ_EPI_NONE>(a, nq, st);
             case AZ_EPI_TWIDDLE: return launch_az_one<R, W, false, AZ_EPI_TWIDDLE>(a, nq, st);
             case AZ_EPI_PHI1: return launch_az_one<R, W, false, AZ_EPI_PHI1>(a, nq, st);
+            case AZ_EPI_TWCOL: return launch_az_one<R, W, false, AZ_EPI_TWCOL>(a, nq, st);
         }
     } else {
         switch (epi) {
             case AZ_EPI_NONE: return launch_az_one<R, W, true, AZ_EPI_NONE>(a, nq, st);
             case AZ_EPI_TWIDDLE: return launch_az_one<R, W, true, AZ_EPI_TWIDDLE>(a, nq, st);
             case AZ_EPI_SCALE: return launch_az_one<R, W, true, AZ_EPI_SCALE>(a, nq, st);
+            case AZ_EPI_PROCOL: return launch_az_one<R, W, true, AZ_EPI_PROCOL>(a, nq, st);
         }
     }
     return hipErrorInvalidValue;

@@ -2,6 +2,7 @@
 // twiddles, scratch), pass orchestration, ATI/DPCA, RCCL all-gather.
 #include "../../include/sarx.h"
 #include "csa_kernels.h"
+#include "general.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -80,6 +81,7 @@ struct sarx_plan {
     float2 *h_in = nullptr, *h_out = nullptr;   // device staging for the *_host entry point
     uint64_t bytes = 0;
     int mark_start = -1, mark_stop = -1;   // ctx event slots recorded around the range pass(es)
+    GeneralCsa* gen = nullptr;             // chirp-z path for sizes that are not powers of two in [16, 16384]
 };
 
 static int fail(sarx_ctx* c, int code, const char* fmt, ...) {
@@ -238,14 +240,28 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
     NEED_CTX(c);
     if (!out || !prm) return fail(c, SARX_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    if (!is_pow2(n_az) || !is_pow2(n_rg) || n_az < 16 || n_rg < 16 || n_az > TW_MAX || n_rg > TW_MAX)
-        return fail(c, SARX_ERR_UNSUPPORTED, "n_az=%d n_rg=%d: sizes must be powers of two in [16, %d]", n_az, n_rg, TW_MAX);
+    if (n_az < 2 || n_rg < 2 || n_az > TW_MAX || n_rg > TW_MAX)
+        return fail(c, SARX_ERR_UNSUPPORTED, "n_az=%d n_rg=%d: sizes must be in [2, %d]", n_az, n_rg, TW_MAX);
     if (flags & ~(SARX_OUT_RG_MAJOR | SARX_FUSE_RANGE)) return fail(c, SARX_ERR_INVALID, "unknown plan flags 0x%x", flags);
+    const bool general = !is_pow2(n_az) || !is_pow2(n_rg) || n_az < 16 || n_rg < 16;
     if (!(prm->sample_rate_hz > 0) || !(prm->prf_hz > 0) || !(prm->platform_speed_mps > 0) ||
         !(prm->wavelength_m > 0) || prm->chirp_rate_hz_s == 0.0)
         return fail(c, SARX_ERR_INVALID, "radar parameters must be positive (chirp rate non-zero)");
     sarx_plan* p = new sarx_plan();
     p->ctx = c; p->n_az = n_az; p->n_rg = n_rg; p->flags = flags; p->p = *prm;
+    if (general) {       // any other size: chirp-z transforms over the power-of-two kernels (general.hip)
+        std::string err;
+        p->gen = general_csa_create(n_az, n_rg, prm, c->tw_all, err);
+        if (!p->gen) { delete p; return fail(c, SARX_ERR_UNSUPPORTED, "n_az=%d n_rg=%d: %s", n_az, n_rg, err.c_str()); }
+        p->bytes = general_csa_bytes(p->gen);
+        if (flags & SARX_OUT_RG_MAJOR) {
+            hipError_t e2 = hipMalloc(&p->buf_a, (size_t)n_az * n_rg * sizeof(float2));
+            if (e2 != hipSuccess) { int rc = fail(c, SARX_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e2)); sarx_csa_plan_destroy(p); return rc; }
+            p->bytes += (size_t)n_az * n_rg * sizeof(float2);
+        }
+        *out = p;
+        return SARX_OK;
+    }
     p->az_s = (n_az <= 128) ? n_az : (1 << (ilog2(n_az) / 2));
     p->az_w = (n_rg % 32 == 0) ? 32 : 16;
     if (const char* e = getenv("SARX_AZ_W")) { const int w = atoi(e); if ((w == 16 || w == 32 || w == 64) && n_rg % w == 0) p->az_w = w; }
@@ -294,6 +310,7 @@ int sarx_csa_plan_destroy(sarx_plan* p) {
     if (!p) return SARX_OK;
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
+    general_csa_destroy(p->gen);
     hipFree(p->c1); hipFree(p->c2); hipFree(p->c3);
     hipFree(p->buf_a); hipFree(p->buf_b); hipFree(p->h_in); hipFree(p->h_out);
     delete p;
@@ -392,6 +409,7 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
     sarx_ctx* c = p->ctx;
     hipSetDevice(c->device);
     if (!d_in || !d_out) return fail(c, SARX_ERR_INVALID, "NULL image pointer");
+    if (p->gen) return fail(c, SARX_ERR_UNSUPPORTED, "per-pass entry points exist for power-of-two plans only");
     switch (pass_id) {
         case SARX_PASS_AZ_FFT_PHI1:
         case SARX_PASS_AZ_IFFT:
@@ -414,6 +432,12 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     if (!d_phist || !d_image || d_phist == d_image) return fail(c, SARX_ERR_INVALID, "image pointers NULL or aliased");
     const bool rg_major = p->flags & SARX_OUT_RG_MAJOR;
     int rc;
+    if (p->gen) {
+        float2* dst = rg_major ? p->buf_a : (float2*)d_image;
+        HIPCHK(c, general_csa_focus(p->gen, (const float2*)d_phist, dst, c->stream));
+        if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
+        return SARX_OK;
+    }
     // pass 1: azimuth FFT + Phi_1: phist -> (image as step-A scratch) -> buf_b
     if ((rc = az_pass(p, false, d_phist, d_image, p->buf_b)) != SARX_OK) return rc;
     // passes 2, 3 in place on buf_b
