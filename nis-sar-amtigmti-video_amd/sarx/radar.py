@@ -30,3 +30,18 @@ def focus_args(n_rg=None, k=None):
     else:
         t0 = 2 * k["R0"] / C - (n_rg / k["FS"]) / 2
     return (k["Lambda"], k["T_p"], k["Kr"], k["FS"], k["PRF"], k["V_eff"], k["R0"], t0)
+
+
+def orbit_track(t_vec, k=None):
+    """Great-circle transmitter positions and velocities over the slow-time vector
+    (sar_ati_dcpa_sim_csa.py:50-66), as [n x 3] arrays."""
+    import numpy as np
+    k = k or reference_constants()
+    R_sat, V_sat, Re, g = k["R_sat"], k["V_sat"], k["Re"], k["gamma_rad"]
+    omega = V_sat / R_sat
+    S0 = np.array([-R_sat * np.sin(g), 0.0, R_sat * np.cos(g)])
+    V_unit = np.array([0.0, 1.0, 0.0])
+    wt = omega * np.asarray(t_vec, dtype=np.float64)[:, None]
+    pos = S0[None, :] * np.cos(wt) + (R_sat * V_unit)[None, :] * np.sin(wt) + np.array([0.0, 0.0, -Re])[None, :]
+    vel = (V_sat * V_unit)[None, :] * np.cos(wt) - (S0 * omega)[None, :] * np.sin(wt)
+    return pos, vel

@@ -15,6 +15,7 @@ values; reference outputs are complex128):
   csa_digest_1024.npz      1024x1024: peak, sampled rows/cols, norms only
   ati_128x128.npz          two-channel scene -> slc1, slc2 + the literal
                            expressions of :414-419,447-449 and viewer :249-250
+  destroyer.npz            generate_destroyer        (vehicle_targets.py:102-141)
   echo_mono.npz            run_physics_engine        (sar_satellite_sim.py:211-305)
   echo_bistatic.npz        run_bistatic_physics_gpu  (sar_ati_dcpa_sim_csa.py:106-181)
 """
@@ -107,6 +108,14 @@ def main():
              slc1_mag=slc1_mag, dpca_mag=dpca_mag, mask=mag_mask, ati_phase_masked=ati_phase_masked,
              cal_phase=cal_phase)
     print("ati_128x128: cal_phase", cal_phase, "mask px", int(mag_mask.sum()))
+
+    # target model: vehicle_targets.py imports cleanly (pure functions)
+    sys.path.insert(0, REF)
+    import vehicle_targets as vt
+    tg = vt.generate_destroyer(center_pos=(3.0, -2.0, 1.0))
+    np.savez_compressed(os.path.join(OUT, "destroyer.npz"), center=np.array([3.0, -2.0, 1.0]),
+                        pos=np.array([x["position"] for x in tg], dtype=np.float64),
+                        rcs=np.array([x["rcs"] for x in tg], dtype=np.float64))
 
     # echo generators, tiny, with scaled module constants injected as globals
     kk = orc.reference_radar_constants()

@@ -64,3 +64,23 @@ def test_product_does_not_import_oracle():
                 with open(os.path.join(dirpath, f)) as fh:
                     src = fh.read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def test_target_model_and_orbit_match_reference():
+    """Host helpers the example script needs: destroyer scatterers against the reference's own
+    vehicle_targets.generate_destroyer output, orbit track against the oracle."""
+    from conftest import load_golden
+    from oracle import csa_oracle as orc
+    from sarx import radar, targets
+    g = load_golden("destroyer.npz")
+    for model in (targets.generate_destroyer(tuple(g["center"])), orc.destroyer_targets(tuple(g["center"]))):
+        assert len(model) == 35
+        np.testing.assert_array_equal(np.array([t["position"] for t in model], dtype=np.float64), g["pos"])
+        np.testing.assert_array_equal(np.array([t["rcs"] for t in model], dtype=np.float64), g["rcs"])
+    t = np.linspace(-0.6, 0.6, 13)
+    a, b = radar.orbit_track(t), orc.orbit_track(t)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    k1, k2 = radar.reference_constants(), orc.reference_radar_constants()
+    for key in ("V_sat", "R0", "Lambda", "V_eff", "Kr", "d_rx"):
+        assert abs(k1[key] - k2[key]) <= 1e-12 * abs(k2[key])
