@@ -15,6 +15,7 @@ values; reference outputs are complex128):
   csa_digest_1024.npz      1024x1024: peak, sampled rows/cols, norms only
   ati_128x128.npz          two-channel scene -> slc1, slc2 + the literal
                            expressions of :414-419,447-449 and viewer :249-250
+  rda_<nr>x<np>.npz        sar_focus_rda             (sar_satellite_sim.py:356-448), all 7 outputs
   destroyer.npz            generate_destroyer        (vehicle_targets.py:102-141)
   echo_mono.npz            run_physics_engine        (sar_satellite_sim.py:211-305)
   echo_bistatic.npz        run_bistatic_physics_gpu  (sar_ati_dcpa_sim_csa.py:106-181)
@@ -108,6 +109,21 @@ def main():
              slc1_mag=slc1_mag, dpca_mag=dpca_mag, mask=mag_mask, ati_phase_masked=ati_phase_masked,
              cal_phase=cal_phase)
     print("ati_128x128: cal_phase", cal_phase, "mask px", int(mag_mask.sum()))
+
+    # Range-Doppler focuser (f3)
+    from scipy.interpolate import interp1d
+    from scipy.signal import convolve
+    from scipy.signal.windows import hamming
+    from oracle import rda_oracle as rda
+    ref_rda = extract("sar_satellite_sim.py", "sar_focus_rda", {"np": np, "convolve": convolve, "hamming": hamming,
+                                                                 "interp1d": interp1d})
+    for (nr, npul, seed) in [(200, 96, 31), (257, 101, 32), (128, 64, 33)]:
+        phist, args = rda.rda_scene(nr, npul, seed=seed)
+        o = quiet(ref_rda, phist.astype(np.complex128), *args)
+        np.savez_compressed(os.path.join(OUT, f"rda_{nr}x{npul}.npz"), phist=phist, args=np.array(args, dtype=np.float64),
+                            image_mag_T=o[0], range_axis_centered=o[1], cross_range_m=o[2], phist_compressed=o[3],
+                            range_doppler=o[4], range_doppler_rcmc=o[5], doppler_freq=o[6])
+        print(f"rda_{nr}x{npul}: peak/mean {o[0].max() / o[0].mean():.1f}")
 
     # target model: vehicle_targets.py imports cleanly (pure functions)
     sys.path.insert(0, REF)

@@ -83,3 +83,18 @@ def test_reference_constants():
     k = orc.reference_radar_constants()
     assert abs(k["V_sat"] - 7701.0) < 5 and abs(k["R0"] - 509.4e3) < 200
     assert abs(k["d_rx"] - 2.567) < 2e-3 and abs(k["Kr"] - 2.5e13) < 1.0
+
+
+@pytest.mark.parametrize("tag", ["rda_200x96", "rda_257x101", "rda_128x64"])
+def test_rda_oracle_matches_reference(tag):
+    from oracle import rda_oracle as rda
+    g = load_golden(tag + ".npz")
+    o = rda.sar_focus_rda(g["phist"], *g["args"])
+    assert o[0].shape == g["image_mag_T"].shape
+    assert orc.rel_l2(o[3], g["phist_compressed"]) < 1e-11
+    assert orc.rel_l2(o[4], g["range_doppler"]) < 1e-11
+    assert orc.rel_l2(o[5], g["range_doppler_rcmc"]) < 1e-11
+    assert orc.rel_l2(o[0], g["image_mag_T"]) < 1e-11
+    np.testing.assert_allclose(o[1], g["range_axis_centered"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(o[2], g["cross_range_m"], rtol=1e-13, atol=1e-9)
+    np.testing.assert_allclose(o[6], g["doppler_freq"], rtol=1e-14, atol=1e-12)
