@@ -33,6 +33,7 @@ extern "C" {
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
+typedef struct sarx_rda_plan sarx_rda_plan;
 
 typedef enum {
     SARX_OK = 0,
@@ -113,6 +114,22 @@ int sarx_csa_pass(sarx_plan* plan, int pass_id, const void* d_in, void* d_out);
 int sarx_csa_plan_mark_range(sarx_plan* plan, int slot_start, int slot_stop);
 /* bytes of HBM scratch the plan holds (two ping-pong images + tables) */
 int sarx_csa_plan_bytes(const sarx_plan* plan, uint64_t* out_bytes);
+
+/* ---- Range-Doppler focus: replaces sar_focus_rda (sar_satellite_sim.py:356-448, and its copies at
+ *      sar_satellite_moving_sim.py:208, sar_vehicle_sim.py:182) --------------------------------------
+ * params carries the function's positional arguments (range_ref_m = range_grp_m, t_start_fast unused).
+ * Images here are [n_pulses x n_ranges] row-major: the memory of the reference's [n_ranges x n_pulses]
+ * argument when it is raw.T, and of the returned sar_image_mag.T.  n_ranges + matched-filter taps - 1
+ * must be <= 32768; a non-power-of-two n_pulses must be <= 8192. */
+int sarx_rda_plan_create(sarx_ctx* ctx, int n_ranges, int n_pulses, const sarx_radar_params* params,
+                         sarx_rda_plan** out_plan);
+int sarx_rda_plan_destroy(sarx_rda_plan* plan);
+/* host in / host out, blocking.  Optional complex64 outputs (NULL = skip): range-compressed data (:392),
+ * range-Doppler map (:399), map after RCMC (:427), each [n_pulses x n_ranges]. */
+int sarx_rda_focus_host(sarx_rda_plan* plan, const void* phist_pulse_major_host, float* image_mag_host,
+                        void* range_compressed_host, void* range_doppler_host, void* range_doppler_rcmc_host);
+/* range_axis_centered[n_ranges] (:443-444), cross_range_m[n_pulses] (:442), doppler_freq[n_pulses] (:402-405) */
+int sarx_rda_axes(const sarx_rda_plan* plan, double* range_axis_centered, double* cross_range_m, double* doppler_freq);
 
 /* ---- ATI / DPCA: replaces the inline expressions of
  *      sar_ati_dcpa_sim_csa.py:414-419,447-449 and

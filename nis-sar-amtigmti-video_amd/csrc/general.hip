@@ -22,12 +22,13 @@
 namespace sarx {
 
 // ---- element-wise kernels --------------------------------------------------------------------------
-// out[r][c] = (r < in_rows && c < in_cols ? in[r*in_ld + c] : 0) * rowvec[r] * colvec[c] * scalar
-// (in may equal out: each thread reads and writes the same element)
+// out[r][c] = (r < in_rows && c < in_cols ? in[s][c] : 0) * rowvec[r] * rowvec_src[s] * colvec[c] * scalar,
+// s = (r + row_shift) mod in_rows  (a circular shift of the rows: fftshift / ifftshift bookkeeping of the RDA)
+// (in may equal out when row_shift == 0: each thread reads and writes the same element)
 __global__ __launch_bounds__(256) void scale_copy_2d_kernel(const cf* in, int in_rows, int in_cols, size_t in_ld,
                                                             cf* out, int out_rows, int out_cols, size_t out_ld,
                                                             const cf* __restrict__ rowvec, const cf* __restrict__ colvec,
-                                                            float scalar) {
+                                                            float scalar, int row_shift, const cf* __restrict__ rowvec_src) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= out_cols) return;
     const bool cin = c < in_cols;
@@ -36,18 +37,22 @@ __global__ __launch_bounds__(256) void scale_copy_2d_kernel(const cf* in, int in
     for (int r = blockIdx.y; r < out_rows; r += gridDim.y) {
         cf x = make_float2(0.f, 0.f);
         if (cin && r < in_rows) {
-            x = cmul(in[(size_t)r * in_ld + c], cv);
+            int s = r + row_shift;
+            if (s >= in_rows) s -= in_rows;
+            x = cmul(in[(size_t)s * in_ld + c], cv);
             if (rowvec) x = cmul(x, rowvec[r]);
+            if (rowvec_src) x = cmul(x, rowvec_src[s]);
         }
         out[(size_t)r * out_ld + c] = x;
     }
 }
 
 static hipError_t scale_copy(const cf* in, int in_rows, int in_cols, size_t in_ld, cf* out, int out_rows, int out_cols,
-                             size_t out_ld, const cf* rowvec, const cf* colvec, float scalar, hipStream_t st) {
+                             size_t out_ld, const cf* rowvec, const cf* colvec, float scalar, hipStream_t st,
+                             int row_shift = 0, const cf* rowvec_src = nullptr) {
     dim3 grid((out_cols + 255) / 256, out_rows < 16384 ? out_rows : 16384);
     hipLaunchKernelGGL(scale_copy_2d_kernel, grid, dim3(256), 0, st, in, in_rows, in_cols, in_ld, out, out_rows, out_cols,
-                       out_ld, rowvec, colvec, scalar);
+                       out_ld, rowvec, colvec, scalar, row_shift, rowvec_src);
     return hipGetLastError();
 }
 
@@ -221,20 +226,26 @@ static hipError_t fft_rows(GeneralCsa* g, cf* d, bool inv, hipStream_t st) {
     return scale_copy(w, B, n, m, d, B, n, n, nullptr, inv ? ax.chirp_i : ax.chirp_f, inv ? 1.0f / (float)n : 1.0f, st);
 }
 
-static hipError_t fft_cols(GeneralCsa* g, const cf* src, cf* dst, bool inv, hipStream_t st) {
+// in_shift / out_shift: circular row shifts applied while copying in / out (element r of the transformed sequence is
+// source row (r + in_shift) mod n; destination row r' receives sequence element (r' + out_shift) mod n);
+// pre: optional per-source-row factor (azimuth window)
+static hipError_t fft_cols(GeneralCsa* g, const cf* src, cf* dst, bool inv, hipStream_t st, int in_shift = 0,
+                           const cf* pre = nullptr, int out_shift = 0) {
     const Axis& ax = g->az;
     const int n = g->n_az, C = g->n_rg, ld = g->ldc, m = ax.m;
     cf *wa = g->work_a, *wb = g->work_b;
     if (ax.direct) {
-        GCK(scale_copy(src, n, C, C, wa, n, ld, ld, nullptr, nullptr, 1.0f, st));
+        GCK(scale_copy(src, n, C, C, wa, n, ld, ld, nullptr, nullptr, 1.0f, st, in_shift, pre));
         GCK(cols_pow2(g, wa, wa, wb, n, ld, inv, st));                     // step A in place on wa, result in wb
-        return scale_copy(wb, n, C, ld, dst, n, C, C, nullptr, nullptr, 1.0f, st);
+        return scale_copy(wb, n, C, ld, dst, n, C, C, nullptr, nullptr, 1.0f, st, out_shift, nullptr);
     }
-    GCK(scale_copy(src, n, C, C, wa, m, ld, ld, inv ? ax.chirp_i : ax.chirp_f, nullptr, 1.0f, st));
+    const cf* chirp = inv ? ax.chirp_i : ax.chirp_f;
+    GCK(scale_copy(src, n, C, C, wa, m, ld, ld, chirp, nullptr, 1.0f, st, in_shift, pre));
     GCK(cols_pow2(g, wa, wa, wb, m, ld, false, st));                       // step A in place on wa, result in wb
     GCK(scale_copy(wb, m, ld, ld, wa, m, ld, ld, inv ? ax.bhat_i : ax.bhat_f, nullptr, 1.0f, st));
     GCK(cols_pow2(g, wa, wa, wb, m, ld, true, st));
-    return scale_copy(wb, n, C, ld, dst, n, C, C, inv ? ax.chirp_i : ax.chirp_f, nullptr, inv ? 1.0f / (float)n : 1.0f, st);
+    // the chirp belongs to the sequence index, i.e. to the source row of this copy
+    return scale_copy(wb, n, C, ld, dst, n, C, C, nullptr, nullptr, inv ? 1.0f / (float)n : 1.0f, st, out_shift, chirp);
 }
 
 template <int WHICH> static hipError_t phase(GeneralCsa* g, cf* d, hipStream_t st) {
@@ -259,6 +270,214 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
     GCK(phase<3>(g, d, st));                       // :359-382
     return fft_cols(g, d, d_out, true, st);        // :385
 }
+
+// =====================================================================================================
+// Range-Doppler focuser: sar_focus_rda, sar_satellite_sim.py:356-448 (pasted again at
+// sar_satellite_moving_sim.py:208 and sar_vehicle_sim.py:182).  Internal layout [pulse][range] (range
+// contiguous): the transpose of the reference's [range][pulse] argument, which the scripts themselves
+// obtain as raw.T, so the host passes the underlying memory through unchanged.
+//   1 range compression: linear convolution with the Hamming-weighted unit-norm chirp, 'same' window
+//     (:375-392) as FFT_M . H . IFFT_M along the lines, M >= n_r + L - 1
+//   2 Hamming over pulses, fftshift . FFT . fftshift along azimuth (:396-399)
+//   3 RCMC: the profile sampled at r(1 - a_k) is read back at r by linear interpolation, 0 outside (:411-427)
+//   4 azimuth compression exp(-i pi fd^2 / Ka(r)) (:431-435)
+//   5 ifftshift . IFFT . ifftshift, magnitude (:438-440)
+// =====================================================================================================
+struct RdaArgsDev {
+    const cf* in;
+    cf* out;
+    float* mag;
+    const double* fd;      // [n_p] Doppler axis (fftshift order, :402-405)
+    const double* r_axis;  // [n_r] range axis in metres (:407)
+    int n_p, n_r;
+    double k_rcmc;         // lambda^2 / (8 Vr^2)
+    double k_ac;           // lambda / (2 Vr^2):  1/Ka = k_ac * r
+};
+// out[k][j] = lerp of in[k][.] at u = (r_j/(1-a_k) - r_0)/dr, zero outside the sampled span
+__global__ __launch_bounds__(256) void rda_rcmc_kernel(RdaArgsDev a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.n_r) return;
+    const double r0 = a.r_axis[0], rj = a.r_axis[j];
+    const double dr = (a.n_r > 1) ? (a.r_axis[a.n_r - 1] - r0) / (double)(a.n_r - 1) : 1.0;
+    for (int k = blockIdx.y; k < a.n_p; k += gridDim.y) {
+        const double alpha = a.fd[k] * a.fd[k] * a.k_rcmc;            // delta_R = r * alpha  (:414)
+        const cf* row = a.in + (size_t)k * a.n_r;
+        cf y = make_float2(0.f, 0.f);
+        if (a.n_r == 1) {
+            y = row[0];
+        } else {
+            const double s = 1.0 - alpha;                            // sample positions x_j' = r_j' * s
+            const double x_first = r0 * s, x_last = a.r_axis[a.n_r - 1] * s;
+            if (rj >= x_first && rj <= x_last) {
+                double u = (rj / s - r0) / dr;
+                int j0 = (int)floor(u);
+                if (j0 < 0) j0 = 0;
+                if (j0 > a.n_r - 2) j0 = a.n_r - 2;
+                // guard the fp rounding of u against the exact sample positions
+                while (j0 > 0 && a.r_axis[j0] * s > rj) --j0;
+                while (j0 < a.n_r - 2 && a.r_axis[j0 + 1] * s <= rj) ++j0;
+                const double xa = a.r_axis[j0] * s, xb = a.r_axis[j0 + 1] * s;
+                const float f = (float)((rj - xa) / (xb - xa));
+                const cf p = row[j0], q = row[j0 + 1];
+                y = make_float2(fmaf(f, q.x - p.x, p.x), fmaf(f, q.y - p.y, p.y));
+            }
+        }
+        a.out[(size_t)k * a.n_r + j] = y;
+    }
+}
+// out = in * exp(-i pi fd_k^2 * k_ac * r_j)
+__global__ __launch_bounds__(256) void rda_azcomp_kernel(RdaArgsDev a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.n_r) return;
+    const double g = -0.5 * a.k_ac * a.r_axis[j];                     // revolutions per Hz^2
+    for (int k = blockIdx.y; k < a.n_p; k += gridDim.y) {
+        const size_t i = (size_t)k * a.n_r + j;
+        a.out[i] = cmul(a.in[i], cis_rev(g * a.fd[k] * a.fd[k]));
+    }
+}
+__global__ __launch_bounds__(256) void rda_mag_kernel(const cf* in, float* mag, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) mag[i] = hypotf(in[i].x, in[i].y);
+}
+
+struct Rda {
+    GeneralCsa* g = nullptr;      // buffers, azimuth axis (n_az = pulses, n_rg = ranges)
+    int n_p = 0, n_r = 0, m_c = 0, l_mf = 0;
+    cf *hhat = nullptr, *win = nullptr;        // filter spectrum [m_c] (split order at 32768), azimuth window [n_p]
+    double *fd = nullptr, *r_axis = nullptr;
+    cf *pc = nullptr, *rd = nullptr, *rc = nullptr;   // the three intermediates the reference returns
+    float* mag = nullptr;
+    std::vector<double> h_fd, h_r;
+    double lam = 0, vr = 0, prf = 0;
+    uint64_t bytes = 0;
+};
+
+void rda_destroy(Rda* r) {
+    if (!r) return;
+    general_csa_destroy(r->g);
+    hipFree(r->hhat); hipFree(r->win); hipFree(r->fd); hipFree(r->r_axis);
+    hipFree(r->pc); hipFree(r->rd); hipFree(r->rc); hipFree(r->mag);
+    delete r;
+}
+
+Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw_all, std::string& err) {
+    // prm: wavelength, pulse width, chirp rate, sample rate, prf, platform speed, range_ref = range_grp_m
+    const double fs = prm->sample_rate_hz, tp = prm->pulse_width_s, kr = prm->chirp_rate_hz_s;
+    const int l_mf = (int)floor(tp / (1.0 / fs)) + 1;                 // :377-378
+    if (l_mf < 1 || n_r < 2 || n_p < 2) { err = "RDA needs n_ranges, n_pulses >= 2 and a positive pulse width"; return nullptr; }
+    int m_c = 16;
+    while (m_c < n_r + l_mf - 1) m_c <<= 1;
+    if (m_c > 32768) { err = "range samples + matched-filter taps - 1 must be <= 32768"; return nullptr; }
+    Rda* r = new Rda();
+    r->n_p = n_p; r->n_r = n_r; r->m_c = m_c; r->l_mf = l_mf;
+    r->lam = prm->wavelength_m; r->vr = prm->platform_speed_mps; r->prf = prm->prf_hz;
+    r->g = general_csa_create(n_p, n_r, prm, tw_all, err);
+    if (!r->g) { delete r; return nullptr; }
+    auto bail = [&](const char* what, hipError_t e) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        rda_destroy(r);
+        return (Rda*)nullptr;
+    };
+    hipError_t e;
+    // the convolution needs [n_p x m_c] work arrays
+    const size_t need = (size_t)n_p * m_c;
+    if (need > r->g->work_elems) {
+        hipFree(r->g->work_a); hipFree(r->g->work_b);
+        r->g->work_a = r->g->work_b = nullptr;
+        if ((e = hipMalloc(&r->g->work_a, need * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
+        if ((e = hipMalloc(&r->g->work_b, need * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
+        r->g->work_elems = need;
+    }
+    // matched filter: conj chirp * Hamming, unit norm (:379-385); its spectrum at length m_c
+    std::vector<zd> h(m_c, zd(0, 0));
+    double nrm = 0;
+    for (int k = 0; k < l_mf; ++k) {
+        const double t = (l_mf > 1) ? -tp / 2 + (double)k * (tp / (double)(l_mf - 1)) : -tp / 2;
+        const double w = (l_mf > 1) ? 0.54 - 0.46 * cos(2.0 * M_PI * (double)k / (double)(l_mf - 1)) : 1.0;
+        h[k] = std::polar(w, -M_PI * kr * t * t);
+        nrm += w * w;
+    }
+    nrm = sqrt(nrm);
+    for (int k = 0; k < l_mf; ++k) h[k] /= nrm;
+    host_fft(h);
+    if (m_c == 32768) {
+        std::vector<zd> p(m_c);
+        for (int k1 = 0; k1 < SPLIT_A; ++k1)
+            for (int k2 = 0; k2 < SPLIT_B; ++k2) p[k1 * SPLIT_B + k2] = h[k1 + SPLIT_A * k2];
+        h.swap(p);
+    }
+    if ((e = upload(h, &r->hhat)) != hipSuccess) return bail("upload filter", e);
+    std::vector<zd> win(n_p);
+    for (int i = 0; i < n_p; ++i) win[i] = zd(n_p > 1 ? 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(n_p - 1)) : 1.0, 0.0);
+    if ((e = upload(win, &r->win)) != hipSuccess) return bail("upload window", e);
+    // axes (:363-373, :402-407)
+    r->h_fd.resize(n_p); r->h_r.resize(n_r);
+    const double t_grp = 2.0 * prm->range_ref_m / 299792458.0;
+    for (int i = 0; i < n_p; ++i) {
+        const double c0 = (n_p % 2 == 0) ? -(double)n_p / 2 : -((double)n_p - 1) / 2;
+        r->h_fd[i] = (c0 + (double)i) * (prm->prf_hz / (double)n_p);
+    }
+    for (int j = 0; j < n_r; ++j) {
+        const double c0 = (n_r % 2 == 0) ? (double)n_r / 2 : ((double)n_r - 1) / 2;
+        r->h_r[j] = (((double)j - c0) / fs + t_grp) * 299792458.0 / 2;
+    }
+    if ((e = hipMalloc(&r->fd, n_p * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&r->r_axis, n_r * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemcpy(r->fd, r->h_fd.data(), n_p * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload", e);
+    if ((e = hipMemcpy(r->r_axis, r->h_r.data(), n_r * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload", e);
+    const size_t img = (size_t)n_p * n_r;
+    if ((e = hipMalloc(&r->pc, img * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&r->rd, img * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&r->rc, img * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&r->mag, img * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    r->bytes = general_csa_bytes(r->g) + img * (3 * sizeof(cf) + sizeof(float));
+    return r;
+}
+
+// d_in: [n_p x n_r] complex64 (the reference's phist transposed).  Results stay in the object's buffers.
+hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st) {
+    GeneralCsa* g = r->g;
+    const int n_p = r->n_p, n_r = r->n_r, m = r->m_c;
+    cf* w = g->work_a;
+    // 1 range compression
+    GCK(scale_copy(d_in, n_p, n_r, n_r, w, n_p, m, m, nullptr, nullptr, 1.0f, st));
+    GCK(rows_pow2(g, w, n_p, m, false, st));
+    GCK(scale_copy(w, n_p, m, m, w, n_p, m, m, nullptr, r->hhat, 1.0f, st));
+    GCK(rows_pow2(g, w, n_p, m, true, st));
+    GCK(scale_copy(w + (r->l_mf - 1) / 2, n_p, n_r, m, r->pc, n_p, n_r, n_r, nullptr, nullptr, 1.0f, st));   // mode='same'
+    // 2 window, fftshift . FFT . fftshift over pulses: roll by h = n_p/2 is source row (r - h) mod n
+    const int h = n_p / 2, sh = (n_p - h) % n_p;
+    GCK(fft_cols(g, r->pc, r->rd, false, st, sh, r->win, sh));
+    // 3, 4
+    RdaArgsDev a{};
+    a.fd = r->fd; a.r_axis = r->r_axis; a.n_p = n_p; a.n_r = n_r;
+    a.k_rcmc = r->lam * r->lam / (8.0 * r->vr * r->vr);
+    a.k_ac = r->lam / (2.0 * r->vr * r->vr);
+    dim3 grid((n_r + 255) / 256, n_p < 16384 ? n_p : 16384);
+    a.in = r->rd; a.out = r->rc;
+    hipLaunchKernelGGL(rda_rcmc_kernel, grid, dim3(256), 0, st, a);
+    GCK(hipGetLastError());
+    a.in = r->rc; a.out = g->data;
+    hipLaunchKernelGGL(rda_azcomp_kernel, grid, dim3(256), 0, st, a);
+    GCK(hipGetLastError());
+    // 5 ifftshift . IFFT . ifftshift: source row (r + h) mod n both ways; magnitude
+    GCK(fft_cols(g, g->data, g->data, true, st, h, nullptr, h));
+    hipLaunchKernelGGL(rda_mag_kernel, dim3(4096), dim3(256), 0, st, g->data, r->mag, (size_t)n_p * n_r);
+    return hipGetLastError();
+}
+
+const float* rda_mag(const Rda* r) { return r->mag; }
+const float2* rda_stage(const Rda* r, int which) { return which == 0 ? r->pc : which == 1 ? r->rd : r->rc; }
+void rda_axes(const Rda* r, double* range_centered, double* cross_range, double* doppler) {
+    double mean = 0;
+    for (double v : r->h_r) mean += v;
+    mean /= (double)r->n_r;
+    if (range_centered) for (int j = 0; j < r->n_r; ++j) range_centered[j] = r->h_r[j] - mean;                 // :443-444
+    if (cross_range) for (int i = 0; i < r->n_p; ++i)
+        cross_range[i] = r->vr * (((double)i - ((r->n_p % 2 == 0) ? (double)r->n_p / 2 : ((double)r->n_p - 1) / 2)) / r->prf);   // :363-366,442
+    if (doppler) for (int i = 0; i < r->n_p; ++i) doppler[i] = r->h_fd[i];
+}
+uint64_t rda_bytes(const Rda* r) { return r->bytes; }
 
 uint64_t general_csa_bytes(const GeneralCsa* g) { return g->bytes; }
 

@@ -478,6 +478,63 @@ int sarx_csa_focus_host(sarx_plan* p, const void* phist_host, void* image_host) 
     return SARX_OK;
 }
 
+// ---- Range-Doppler focus ---------------------------------------------------------------
+struct sarx_rda_plan {
+    sarx_ctx* ctx = nullptr;
+    Rda* r = nullptr;
+    int n_r = 0, n_p = 0;
+    float2* d_in = nullptr;
+};
+
+int sarx_rda_plan_create(sarx_ctx* c, int n_ranges, int n_pulses, const sarx_radar_params* prm, sarx_rda_plan** out) {
+    NEED_CTX(c);
+    if (!out || !prm) return fail(c, SARX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_ranges < 2 || n_pulses < 2 || n_ranges > TW_MAX || n_pulses > TW_MAX)
+        return fail(c, SARX_ERR_UNSUPPORTED, "n_ranges=%d n_pulses=%d: sizes must be in [2, %d]", n_ranges, n_pulses, TW_MAX);
+    if (!(prm->sample_rate_hz > 0) || !(prm->prf_hz > 0) || !(prm->platform_speed_mps > 0) || !(prm->wavelength_m > 0) ||
+        !(prm->pulse_width_s > 0))
+        return fail(c, SARX_ERR_INVALID, "radar parameters must be positive");
+    std::string err;
+    Rda* r = rda_create(n_ranges, n_pulses, prm, c->tw_all, err);
+    if (!r) return fail(c, SARX_ERR_UNSUPPORTED, "n_ranges=%d n_pulses=%d: %s", n_ranges, n_pulses, err.c_str());
+    sarx_rda_plan* p = new sarx_rda_plan();
+    p->ctx = c; p->r = r; p->n_r = n_ranges; p->n_p = n_pulses;
+    hipError_t e = hipMalloc(&p->d_in, (size_t)n_ranges * n_pulses * sizeof(float2));
+    if (e != hipSuccess) { rda_destroy(r); delete p; return fail(c, SARX_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    *out = p;
+    return SARX_OK;
+}
+int sarx_rda_plan_destroy(sarx_rda_plan* p) {
+    if (!p) return SARX_OK;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    rda_destroy(p->r);
+    hipFree(p->d_in);
+    delete p;
+    return SARX_OK;
+}
+int sarx_rda_focus_host(sarx_rda_plan* p, const void* phist, float* mag, void* pc, void* rd, void* rc) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!phist || !mag) return fail(c, SARX_ERR_INVALID, "NULL host pointer");
+    const size_t px = (size_t)p->n_r * p->n_p;
+    HIPCHK(c, hipMemcpyAsync(p->d_in, phist, px * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, rda_focus(p->r, p->d_in, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mag, rda_mag(p->r), px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    void* outs[3] = {pc, rd, rc};
+    for (int i = 0; i < 3; ++i)
+        if (outs[i]) HIPCHK(c, hipMemcpyAsync(outs[i], rda_stage(p->r, i), px * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SARX_OK;
+}
+int sarx_rda_axes(const sarx_rda_plan* p, double* range_centered, double* cross_range, double* doppler) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    rda_axes(p->r, range_centered, cross_range, doppler);
+    return SARX_OK;
+}
+
 // ---- ATI / DPCA ------------------------------------------------------------------
 int sarx_ati_dpca_dev(sarx_ctx* c, const void* s1, const void* s2, size_t n, double cal_phase,
                       const sarx_ati_outputs* o, double* max_mag, double* sum2) {

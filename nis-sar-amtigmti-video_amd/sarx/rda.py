@@ -1,0 +1,46 @@
+"""Range-Doppler focuser with the reference's signature:
+``sar_focus_rda`` of sar_satellite_sim.py:356-448 (pasted again in sar_satellite_moving_sim.py:208 and
+sar_vehicle_sim.py:182)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check
+from .engine import default_context
+
+
+def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+                  platform_speed_mps, range_grp_m, *, ctx=None, intermediates=True):
+    """phist: [num_ranges x num_pulses] complex (the scripts pass ``raw_data.T``).
+
+    Returns the reference's 7-tuple (:447-448): (sar_image_mag.T [pulses x ranges], range_axis_centered,
+    cross_range_m, phist_compressed, range_doppler, range_doppler_rcmc [ranges x pulses each], doppler_freq).
+    Images are float32 / complex64.  ``intermediates=False`` skips downloading the three complex maps
+    (they come back as None).
+    """
+    a = np.asarray(phist)
+    if a.ndim != 2:
+        raise ValueError("phist must be 2-D [num_ranges x num_pulses]")
+    n_r, n_p = a.shape
+    ctx = ctx or default_context()
+    lib = ctx.lib
+    # pulse-major memory: free when phist is the usual raw.T view
+    x = np.ascontiguousarray(a.T, dtype=np.complex64)
+    prm = _ffi.RadarParams(center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+                           platform_speed_mps, range_grp_m, 0.0)
+    h = C.c_void_p()
+    check(lib.sarx_rda_plan_create(ctx.h, n_r, n_p, C.byref(prm), C.byref(h)), ctx.h)
+    try:
+        mag = np.empty((n_p, n_r), dtype=np.float32)
+        stages = [np.empty((n_p, n_r), dtype=np.complex64) if intermediates else None for _ in range(3)]
+        ptr = [s.ctypes.data if s is not None else None for s in stages]
+        check(lib.sarx_rda_focus_host(h, x.ctypes.data, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
+        r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
+        check(lib.sarx_rda_axes(h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
+    finally:
+        lib.sarx_rda_plan_destroy(h)
+    pc, rd, rc = (s.T if s is not None else None for s in stages)
+    return mag, r_ax, c_ax, pc, rd, rc, fd

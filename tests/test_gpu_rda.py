@@ -1,0 +1,66 @@
+"""Range-Doppler focuser on the GPU against the reference's own outputs
+(tests/golden/rda_*.npz, written by oracle/make_golden.py from sar_satellite_sim.py:356-448) and against
+oracle/rda_oracle.py at sizes the fixtures do not cover.  Tolerance: relative L2 <= 1e-4 for complex64
+(the bar BASELINE.json states for the hot path); axes are float64 and compared to 1e-9 relative."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rda_oracle as rda
+from oracle.csa_oracle import rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+def _check(out, ref):
+    mag, r_ax, c_ax, pc, rd, rc, fd = out
+    rmag, rr, rcx, rpc, rrd, rrc, rfd = ref
+    assert mag.shape == rmag.shape and pc.shape == rpc.shape
+    assert rel_l2(pc, rpc) < TOL, "range compression"
+    assert rel_l2(rd, rrd) < TOL, "range-Doppler map"
+    assert rel_l2(rc, rrc) < TOL, "RCMC"
+    assert rel_l2(mag, rmag) < TOL, "image"
+    np.testing.assert_allclose(r_ax, rr, rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(c_ax, rcx, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(fd, rfd, rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["rda_200x96", "rda_257x101", "rda_128x64"])
+def test_rda_golden(name):
+    import sarx
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    out = sarx.sar_focus_rda(g["phist"], *[float(v) for v in g["args"]])
+    ref = (g["image_mag_T"], g["range_axis_centered"], g["cross_range_m"], g["phist_compressed"], g["range_doppler"],
+           g["range_doppler_rcmc"], g["doppler_freq"])
+    _check(out, ref)
+
+
+@pytest.mark.parametrize("n_r,n_p", [(1024, 512), (1500, 700), (4096, 2048)])
+def test_rda_oracle(n_r, n_p):
+    import sarx
+    phist, args = rda.rda_scene(n_r, n_p, seed=n_r + n_p)
+    out = sarx.sar_focus_rda(phist, *args)
+    _check(out, rda.sar_focus_rda(phist, *args))
+
+
+def test_rda_view_input_and_no_intermediates():
+    """raw.T (a view) as the scripts pass it; intermediates=False returns None for the three maps."""
+    import sarx
+    phist, args = rda.rda_scene(256, 128, seed=9)
+    raw = np.ascontiguousarray(phist.T)
+    out = sarx.sar_focus_rda(raw.T, *args, intermediates=False)
+    assert out[3] is None and out[4] is None and out[5] is None
+    assert rel_l2(out[0], rda.sar_focus_rda(phist, *args)[0]) < TOL
+
+
+def test_rda_errors():
+    import sarx
+    phist, args = rda.rda_scene(64, 32, seed=1)
+    with pytest.raises(ValueError):
+        sarx.sar_focus_rda(phist[0], *args)
+    bad = list(args); bad[4] = 0.0
+    with pytest.raises(sarx.SarxError):
+        sarx.sar_focus_rda(phist, *bad)
