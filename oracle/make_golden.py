@@ -19,6 +19,8 @@ values; reference outputs are complex128):
   destroyer.npz            generate_destroyer        (vehicle_targets.py:102-141)
   echo_mono.npz            run_physics_engine        (sar_satellite_sim.py:211-305)
   echo_bistatic.npz        run_bistatic_physics_gpu  (sar_ati_dcpa_sim_csa.py:106-181)
+  spot_<a|b>.npz           run_physics_spotlight     (sar_batch_sim.py:85-169) + calculate_raw_snr_db (:54-64)
+  tdbp_<a|b>.npz           tdbp_gpu                  (sar_batch_sim.py:171-238), moving-target and static focus
 """
 import ast
 import contextlib
@@ -161,6 +163,46 @@ def main():
         print("echo_bistatic:", raw_b.shape, np.abs(raw_b).max())
     except ImportError:
         print("torch missing: echo_bistatic.npz not regenerated")
+    make_tdbp()
+
+
+def make_tdbp():
+    """spot_*.npz / tdbp_*.npz: run_physics_spotlight (:85-169) and tdbp_gpu (:171-238) of sar_batch_sim.py,
+    torch on the CPU, module constants injected (two scaled radars)."""
+    import torch
+    from oracle import tdbp_oracle as tb
+    cases = [("a", tb.scaled_constants(), dict(n_pulses=96, seed=3, speed=15.0, heading_deg=30.0, swath=400.0), 48, 40),
+             ("b", tb.scaled_constants(fs=90e6, t_p=1.5e-6, bw=75e6, prf=4000.0),
+              dict(n_pulses=70, seed=5, speed=120.0, heading_deg=135.0, swath=300.0), 33, 37)]
+    for tag, k, kw, nx, ny in cases:
+        env = {"np": np, "torch": torch, "device": torch.device("cpu")}
+        env.update({n: k[n] for n in ("C", "FC", "FS", "T_P", "K_RATE", "R0", "Lambda", "P_TX", "ANT_WIDTH", "T_SYS",
+                                      "NF_DB", "LOSS_DB", "K_BOLTZ")})
+        spot = extract("sar_batch_sim.py", "run_physics_spotlight", env)
+        tdbp = extract("sar_batch_sim.py", "tdbp_gpu", env)
+        snr = extract("sar_batch_sim.py", "calculate_raw_snr_db", env)
+        sc = tb.tdbp_scene(k=k, **kw)
+        raw_t, t_start, n, v_tgt = spot(sc["targets"], sc["t_vec"], sc["pos"], sc["vel"], heading_deg=sc["heading_deg"],
+                                        speed=sc["speed"], l_ant=sc["l_ant"])
+        raw = raw_t.numpy()
+        consts = np.array([k[n] for n in ("C", "FC", "FS", "T_P", "K_RATE", "R0", "Lambda", "PRF", "BW")])
+        np.savez_compressed(os.path.join(OUT, f"spot_{tag}.npz"), consts=consts, raw=raw, t_start=t_start, num_samples=n,
+                            v_tgt=v_tgt, t_vec=sc["t_vec"], pos=sc["pos"], vel=sc["vel"], l_ant=sc["l_ant"],
+                            heading_deg=sc["heading_deg"], speed=sc["speed"],
+                            tgt_pos=np.array([t["position"] for t in sc["targets"]]),
+                            tgt_rcs=np.array([t["rcs"] for t in sc["targets"]]),
+                            snr_db=snr(k["R0"], 5000.0, k["Lambda"], k["BW"], sc["l_ant"]))
+        # the input the focuser sees is complex64 (what the GPU path takes); both focus velocities of the script
+        raw64 = raw.astype(np.complex64)
+        out = {}
+        for name, vf in (("mbp", v_tgt), ("stdbp", np.zeros(3))):
+            out[name] = tdbp(torch.tensor(raw64.astype(np.complex128)), sc["pos"], sc["vel"], t_start, n, vel_focus=vf,
+                             t_pulses=sc["t_vec"], scene_size=sc["swath"], nx=nx, ny=ny)
+        np.savez_compressed(os.path.join(OUT, f"tdbp_{tag}.npz"), consts=consts, raw=raw64, t_start=t_start, num_samples=n,
+                            v_tgt=v_tgt, t_vec=sc["t_vec"], pos=sc["pos"], vel=sc["vel"], swath=sc["swath"], nx=nx, ny=ny,
+                            img_mbp=out["mbp"], img_stdbp=out["stdbp"])
+        print(f"tdbp_{tag}: raw {raw.shape}, image {out['mbp'].shape}, peak {np.abs(out['mbp']).max():.4g} / "
+              f"{np.abs(out['stdbp']).max():.4g}")
 
 
 if __name__ == "__main__":
