@@ -34,6 +34,7 @@ extern "C" {
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
 typedef struct sarx_rda_plan sarx_rda_plan;
+typedef struct sarx_tdbp_plan sarx_tdbp_plan;
 
 typedef enum {
     SARX_OK = 0,
@@ -178,6 +179,36 @@ int sarx_fill_noise_c64(sarx_ctx* ctx, void* d_buf, size_t n, uint64_t seed);
 int sarx_echo_synth_dev(sarx_ctx* ctx, const double* d_tau_pb, const float* d_amp, const double* d_t_fast,
                         int n_pulses, int n_targets, int n_samples, double chirp_rate_hz_s, double pulse_width_s,
                         void* d_raw);
+
+/* run_physics_spotlight (sar_batch_sim.py:85-169), sample loop :145-149: as above with u = t_fast[j]-tau[i][b]
+ * (no Tp/2 offset) and an amplitude per pulse and target, d_amp_pt [n_pulses][n_targets] float = rcs * antenna gain */
+int sarx_echo_spotlight_dev(sarx_ctx* ctx, const double* d_tau_pb, const float* d_amp_pt, const double* d_t_fast,
+                            int n_pulses, int n_targets, int n_samples, double chirp_rate_hz_s, double pulse_width_s,
+                            void* d_raw);
+
+/* ---- time-domain back-projection: replaces tdbp_gpu (sar_batch_sim.py:171-238) ---------------------
+ * The module constants the reference function reads (sar_batch_sim.py:13,20,23-25). */
+typedef struct {
+    double c;        /* C      propagation speed, m/s */
+    double fc;       /* FC     carrier, Hz */
+    double fs;       /* FS     sample rate, Hz */
+    double t_p;      /* T_P    pulse width, s: the reference chirp has int(T_P*FS) taps (:177) */
+    double k_rate;   /* K_RATE chirp rate, Hz/s */
+} sarx_tdbp_params;
+/* A plan owns the reference-chirp spectrum and all device scratch for [n_pulses x num_samples] complex64 pulses
+ * and an [ny x nx] image.  The reference chirp may have at most 16385 taps. */
+int sarx_tdbp_plan_create(sarx_ctx* ctx, int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp_params* k,
+                          sarx_tdbp_plan** out_plan);
+int sarx_tdbp_plan_destroy(sarx_tdbp_plan* plan);
+/* raw [n_pulses][num_samples] complex64; pos, vel [n_pulses][3], t_pulses [n_pulses], vel_focus [3]: HOST doubles
+ * (tdbp_gpu's pos_plat, vel_plat, t_pulses, vel_focus); image [ny][nx] complex128 as the reference returns it.
+ * _dev: raw and image are device pointers, asynchronous on the ctx stream after the small geometry upload.
+ * _host: blocking; range_compressed_host (optional, complex64 [n_pulses][num_samples]) receives rc_data (:185). */
+int sarx_tdbp_focus_dev(sarx_tdbp_plan* plan, const void* d_raw, const double* pos, const double* vel,
+                        const double* t_pulses, double t_start, const double* vel_focus, double scene_size, void* d_image);
+int sarx_tdbp_focus_host(sarx_tdbp_plan* plan, const void* raw_host, const double* pos, const double* vel,
+                         const double* t_pulses, double t_start, const double* vel_focus, double scene_size,
+                         void* image_host, void* range_compressed_host);
 
 /* ---- multi-GPU: RCCL all-gather of the image stack over xGMI ------------- */
 #define SARX_COMM_ID_BYTES 128

@@ -79,9 +79,10 @@ hipError_t launch_fill_noise(float2* buf, size_t n, uint64_t seed, hipStream_t s
 struct EchoArgs {
     const double2* tau_pb;   // [n_pulses][n_targets] {delay s, carrier phase in revolutions}
     const float* amp;        // [n_targets] sqrt(rcs)
+    const float* amp_pt;     // optional [n_pulses][n_targets]: per-pulse amplitude (antenna pattern), replaces amp
     const double* t_fast;    // [n_samples] absolute fast time of each sample
     float2* out;             // [n_pulses][n_samples]
-    double kr, t_p;
+    double kr, t_p, u_off;   // u = t_fast - tau - u_off
     int n_pulses, n_targets, n_samples;
 };
 hipError_t launch_echo_synth(const EchoArgs& a, hipStream_t st);

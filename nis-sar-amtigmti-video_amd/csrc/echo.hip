@@ -10,6 +10,8 @@
 // the fast-time grid exactly as the reference builds it (linspace, :254 / :113).  The
 // kernel does the n_pulses x n_targets x n_samples work: one thread per sample, targets
 // staged through LDS, phase summed and reduced in fp64, sine/cosine and accumulation fp32.
+// run_physics_spotlight (sar_batch_sim.py:145-149) is the same loop with u = t_fast - tau (no Tp/2 offset)
+// and an amplitude per pulse and target (rcs times the antenna pattern): amp_pt, u_off = 0.
 // Compute-bound (28 issue slots per target-sample, no reuse of HBM data), so no roofline
 // in bytes: 5000 targets x 7200 x 13200 = 4.8e11 target-samples.
 #include "csa_kernels.h"
@@ -35,12 +37,12 @@ __global__ __launch_bounds__(ECHO_THREADS) void echo_synth_kernel(EchoArgs a) {
             const double2 tp = a.tau_pb[(size_t)i * a.n_targets + b];
             s_tau[threadIdx.x] = tp.x;
             s_pb[threadIdx.x] = tp.y;
-            s_amp[threadIdx.x] = a.amp[b];
+            s_amp[threadIdx.x] = a.amp_pt ? a.amp_pt[(size_t)i * a.n_targets + b] : a.amp[b];
         }
         __syncthreads();
         const int nb = min(ECHO_THREADS, a.n_targets - b0);
         for (int k = 0; k < nb; ++k) {
-            const double u = (tf - s_tau[k]) - half_tp;          // (:290,293 / :164,166)
+            const double u = (tf - s_tau[k]) - a.u_off;          // (:290,293 / :164,166)
             const float gate = (fabs(u) <= half_tp) ? s_amp[k] : 0.f;
             const cf e = cis_rev(fma(hk * u, u, s_pb[k]));      // phase_base + pi k u^2, in revolutions
             acc_re = fmaf(gate, e.x, acc_re);

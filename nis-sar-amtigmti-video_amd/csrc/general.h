@@ -1,6 +1,8 @@
 // Any-size CSA focus (chirp-z over the power-of-two kernels); see general.hip.
 #pragma once
+#include <complex>
 #include <string>
+#include <vector>
 
 #include "../../include/sarx.h"
 #include "csa_kernels.h"
@@ -11,6 +13,16 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
 void general_csa_destroy(GeneralCsa* g);
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st);
 uint64_t general_csa_bytes(const GeneralCsa* g);
+
+// building blocks shared with tdbp.hip
+// in-place line FFTs of `rows` contiguous lines of length m (power of two, 16..32768); the inverse carries 1/m.
+// m == 32768 leaves the spectrum in the split order of to_split_order(); the inverse expects that order.
+hipError_t line_fft_pow2(const float2* tw_all, float2* buf, int rows, int m, bool inv, hipStream_t st);
+void host_fft_pow2(std::vector<std::complex<double>>& a);         // forward, in place
+void to_split_order(std::vector<std::complex<double>>& a);        // 32768-point spectrum: natural -> device order
+// out[r][c] = (r < in_rows && c < in_cols ? in[r][c] : 0) * colvec[c] * scalar   (colvec optional)
+hipError_t scale_copy_cols(const float2* in, int in_rows, int in_cols, size_t in_ld, float2* out, int out_rows, int out_cols,
+                           size_t out_ld, const float2* colvec, float scalar, hipStream_t st);
 
 // Range-Doppler focuser (sar_satellite_sim.py:356-448); params.range_ref_m carries range_grp_m
 struct Rda;

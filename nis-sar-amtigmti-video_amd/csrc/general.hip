@@ -211,6 +211,23 @@ static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n
     return launch_az_tile(S, 32, inv, epi_last, a, RA, st);
 }
 
+hipError_t line_fft_pow2(const float2* tw_all, float2* buf, int rows, int m, bool inv, hipStream_t st) {
+    GeneralCsa g;
+    g.tw_all = tw_all;
+    return rows_pow2(&g, buf, rows, m, inv, st);
+}
+void host_fft_pow2(std::vector<zd>& a) { host_fft(a); }
+void to_split_order(std::vector<zd>& a) {
+    std::vector<zd> p(a.size());
+    for (int k1 = 0; k1 < SPLIT_A; ++k1)
+        for (int k2 = 0; k2 < SPLIT_B; ++k2) p[k1 * SPLIT_B + k2] = a[k1 + SPLIT_A * k2];
+    a.swap(p);
+}
+hipError_t scale_copy_cols(const float2* in, int in_rows, int in_cols, size_t in_ld, float2* out, int out_rows, int out_cols,
+                           size_t out_ld, const float2* colvec, float scalar, hipStream_t st) {
+    return scale_copy(in, in_rows, in_cols, in_ld, out, out_rows, out_cols, out_ld, nullptr, colvec, scalar, st);
+}
+
 // ---- any-length transforms of the dense [n_az x n_rg] image `d` (in place) ----------------------------------
 #define GCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 

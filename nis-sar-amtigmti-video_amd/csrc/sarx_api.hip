@@ -3,6 +3,7 @@
 #include "../../include/sarx.h"
 #include "csa_kernels.h"
 #include "general.h"
+#include "tdbp.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -592,8 +593,84 @@ int sarx_echo_synth_dev(sarx_ctx* c, const double* tau_pb, const float* amp, con
         return fail(c, SARX_ERR_INVALID, "echo sizes must be positive (n_pulses <= 65535 per call)");
     EchoArgs a{};
     a.tau_pb = (const double2*)tau_pb; a.amp = amp; a.t_fast = t_fast; a.out = (float2*)raw;
-    a.kr = kr; a.t_p = t_p; a.n_pulses = n_pulses; a.n_targets = n_targets; a.n_samples = n_samples;
+    a.kr = kr; a.t_p = t_p; a.u_off = 0.5 * t_p; a.n_pulses = n_pulses; a.n_targets = n_targets; a.n_samples = n_samples;
     HIPCHK(c, launch_echo_synth(a, c->stream));
+    return SARX_OK;
+}
+int sarx_echo_spotlight_dev(sarx_ctx* c, const double* tau_pb, const float* amp_pt, const double* t_fast, int n_pulses,
+                            int n_targets, int n_samples, double kr, double t_p, void* raw) {
+    NEED_CTX(c);
+    if (!tau_pb || !amp_pt || !t_fast || !raw) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (n_pulses <= 0 || n_targets <= 0 || n_samples <= 0 || n_pulses > 65535)
+        return fail(c, SARX_ERR_INVALID, "echo sizes must be positive (n_pulses <= 65535 per call)");
+    EchoArgs a{};
+    a.tau_pb = (const double2*)tau_pb; a.amp_pt = amp_pt; a.t_fast = t_fast; a.out = (float2*)raw;
+    a.kr = kr; a.t_p = t_p; a.u_off = 0.0; a.n_pulses = n_pulses; a.n_targets = n_targets; a.n_samples = n_samples;
+    HIPCHK(c, launch_echo_synth(a, c->stream));
+    return SARX_OK;
+}
+
+// ---- time-domain back-projection ---------------------------------------------------------
+struct sarx_tdbp_plan {
+    sarx_ctx* ctx = nullptr;
+    Tdbp* t = nullptr;
+    int n_p = 0, n_s = 0, nx = 0, ny = 0;
+    float2* d_raw = nullptr;       // staging for the host entry point
+};
+
+int sarx_tdbp_plan_create(sarx_ctx* c, int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp_params* k,
+                          sarx_tdbp_plan** out) {
+    NEED_CTX(c);
+    if (!out || !k) return fail(c, SARX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_pulses < 1 || num_samples < 2 || nx < 1 || ny < 1 || nx > 65536 || ny > 65536)
+        return fail(c, SARX_ERR_INVALID, "n_pulses=%d num_samples=%d nx=%d ny=%d: sizes must be positive", n_pulses, num_samples, nx, ny);
+    if (!(k->c > 0) || !(k->fc > 0) || !(k->fs > 0) || !(k->t_p > 0) || !(k->k_rate != 0))
+        return fail(c, SARX_ERR_INVALID, "TDBP constants must be positive");
+    std::string err;
+    Tdbp* t = tdbp_create(n_pulses, num_samples, nx, ny, k, c->tw_all, err);
+    if (!t) return fail(c, SARX_ERR_UNSUPPORTED, "tdbp plan: %s", err.c_str());
+    sarx_tdbp_plan* p = new sarx_tdbp_plan();
+    p->ctx = c; p->t = t; p->n_p = n_pulses; p->n_s = num_samples; p->nx = nx; p->ny = ny;
+    *out = p;
+    return SARX_OK;
+}
+int sarx_tdbp_plan_destroy(sarx_tdbp_plan* p) {
+    if (!p) return SARX_OK;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    tdbp_destroy(p->t);
+    hipFree(p->d_raw);
+    delete p;
+    return SARX_OK;
+}
+int sarx_tdbp_focus_dev(sarx_tdbp_plan* p, const void* d_raw, const double* pos, const double* vel, const double* t_pulses,
+                        double t_start, const double* vel_focus, double scene_size, void* d_image) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!d_raw || !pos || !vel || !t_pulses || !vel_focus || !d_image) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (!(scene_size > 0)) return fail(c, SARX_ERR_INVALID, "scene_size must be positive");
+    HIPCHK(c, tdbp_range_compress(p->t, (const float2*)d_raw, c->stream));
+    HIPCHK(c, tdbp_backproject(p->t, pos, vel, t_pulses, t_start, vel_focus, scene_size, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_image, tdbp_image(p->t), (size_t)p->nx * p->ny * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    return SARX_OK;
+}
+int sarx_tdbp_focus_host(sarx_tdbp_plan* p, const void* raw, const double* pos, const double* vel, const double* t_pulses,
+                         double t_start, const double* vel_focus, double scene_size, void* image, void* range_compressed) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!raw || !pos || !vel || !t_pulses || !vel_focus || !image) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (!(scene_size > 0)) return fail(c, SARX_ERR_INVALID, "scene_size must be positive");
+    const size_t n = (size_t)p->n_p * p->n_s;
+    if (!p->d_raw) HIPCHK(c, hipMalloc(&p->d_raw, n * sizeof(float2)));
+    HIPCHK(c, hipMemcpyAsync(p->d_raw, raw, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, tdbp_range_compress(p->t, p->d_raw, c->stream));
+    HIPCHK(c, tdbp_backproject(p->t, pos, vel, t_pulses, t_start, vel_focus, scene_size, c->stream));
+    HIPCHK(c, hipMemcpyAsync(image, tdbp_image(p->t), (size_t)p->nx * p->ny * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    if (range_compressed) HIPCHK(c, hipMemcpyAsync(range_compressed, tdbp_rc(p->t), n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SARX_OK;
 }
 

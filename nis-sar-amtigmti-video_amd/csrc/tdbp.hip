@@ -1,0 +1,241 @@
+// Time-domain back-projection for the VideoSAR batch: tdbp_gpu, sar_batch_sim.py:171-238.
+//
+//   1 range compression (:180-185): circular correlation of every pulse [num_samples] with the fftshifted
+//     reference chirp (int(T_P*FS) taps).  num_samples is 22004 = 4 * 5501 natively, so the correlation
+//     runs as overlap-save blocks on the power-of-two line FFT (M <= 32768): block b produces outputs
+//     [b*B, b*B + B), B = M - taps + 1, from the wrapped input segment starting at b*B.
+//   2 back-projection (:197-236): for every pixel and pulse the two-way delay with the receiver moved by
+//     the platform during the flight time (:216-220), the range-Doppler coupling shift (:209-213), a linear
+//     interpolation of the compressed pulse and the carrier phase exp(j 2 pi FC tau) (:231), summed over
+//     pulses.  Geometry and phase argument in fp64 (FC*tau = 3e7 revolutions); the interpolation
+//     coordinate goes through float32 exactly as the reference's F.grid_sample call does (:223-226:
+//     normalise, cast, unnormalise with one fused multiply-add), because that quantisation (1e-3 sample)
+//     is visible at the 1e-4 parity bar; samples fp32, pulse sum fp64.
+//     One thread per pixel (16 x 16 pixel tiles keep a wave's gather inside a few hundred bytes of one
+//     pulse), pulses split into chunks across blockIdx.y, partial images reduced in a fixed order.
+//     Compute-bound: ~90 fp64 instructions per pixel-pulse, 6.6e8 pixel-pulses per 512 x 512 x 2500 frame.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#include "fft_core.hpp"
+#include "general.h"
+#include "tdbp.h"
+
+namespace sarx {
+
+typedef std::complex<double> zd;
+
+struct PulseGeo {            // one 64-byte record per pulse, read with scalar loads
+    double px, py, pz;       // platform position
+    double wx, wy, wz;       // platform velocity - focus velocity  (v_rel, :211)
+    double dt, pad;          // t_pulse - mean(t_pulses)            (:203-204)
+};
+
+struct TdbpArgs {
+    const cf* rc;            // [n_p][n_s] range-compressed pulses
+    const PulseGeo* geo;
+    const double *xax, *yax;
+    double2* part;           // [chunks][ny*nx]
+    double vfx, vfy, vfz;
+    double inv_c, fc, fs, t_start, k_shift, inv_ns;
+    float half_w;
+    int n_p, n_s, nx, ny, per_chunk;
+};
+
+__global__ __launch_bounds__(256) void wrap_copy_kernel(const cf* in, int rows, int n, cf* out, int m, int col0) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int s = (col0 + j) % n;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) out[(size_t)r * m + j] = in[(size_t)r * n + s];
+}
+
+__global__ __launch_bounds__(256) void tdbp_kernel(TdbpArgs a) {
+    const int tiles_x = (a.nx + 15) >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int ix = tx * 16 + (threadIdx.x & 15), iy = ty * 16 + (threadIdx.x >> 4);
+    const bool live = ix < a.nx && iy < a.ny;
+    const double gx0 = a.xax[live ? ix : 0], gy0 = a.yax[live ? iy : 0];
+    const int p0 = blockIdx.y * a.per_chunk, p1 = min(a.n_p, p0 + a.per_chunk);
+    double acc_re = 0.0, acc_im = 0.0;
+    for (int p = p0; p < p1; ++p) {
+        const PulseGeo g = a.geo[p];
+        // pixel moved with the focus velocity (:205), vector to the transmitter (:207-208)
+        const double dx = fma(a.vfx, g.dt, gx0) - g.px;
+        const double dy = fma(a.vfy, g.dt, gy0) - g.py;
+        const double dz = a.vfz * g.dt - g.pz;
+        const double d_tx = sqrt(fma(dx, dx, fma(dy, dy, dz * dz)));
+        const double inv_d = 1.0 / d_tx;
+        const double v_rad = (g.wx * dx + g.wy * dy + g.wz * dz) * inv_d;                  // :210-212
+        const double t_shift = v_rad * a.k_shift;                                           // :213
+        const double tau_a = 2.0 * d_tx * a.inv_c;                                          // :215
+        // (g + v_f tau_a) - (pos + vel tau_a) = d - v_rel tau_a                           (:216-218)
+        const double ex = fma(-g.wx, tau_a, dx), ey = fma(-g.wy, tau_a, dy), ez = fma(-g.wz, tau_a, dz);
+        const double d_rx = sqrt(fma(ex, ex, fma(ey, ey, ez * ez)));
+        const double tau = (d_tx + d_rx) * a.inv_c;                                         // :219
+        const double idx_f = (tau - a.t_start + t_shift) * a.fs;                            // :221
+        const float xn = (float)(2.0 * (idx_f * a.inv_ns) - 1.0);                           // :222, .float() :226
+        const float x = __fmaf_rn(xn + 1.0f, a.half_w, -0.5f);                              // grid_sample unnormalise
+        const float x0 = floorf(x);
+        const float w = x - x0, e = 1.0f - w;
+        const int i0 = (int)x0;
+        const cf* row = a.rc + (size_t)p * a.n_s;
+        cf v0 = make_float2(0.f, 0.f), v1 = v0;
+        if (i0 >= 0 && i0 < a.n_s) v0 = row[i0];
+        if (i0 + 1 >= 0 && i0 + 1 < a.n_s) v1 = row[i0 + 1];
+        const float s_re = fmaf(v1.x, w, v0.x * e), s_im = fmaf(v1.y, w, v0.y * e);
+        const cf ph = cis_rev(a.fc * tau);                                                  // :231-232
+        acc_re += (double)(s_re * ph.x - s_im * ph.y);
+        acc_im += (double)(s_re * ph.y + s_im * ph.x);
+    }
+    if (live) a.part[(size_t)blockIdx.y * a.nx * a.ny + (size_t)iy * a.nx + ix] = make_double2(acc_re, acc_im);
+}
+
+__global__ __launch_bounds__(256) void tdbp_reduce_kernel(const double2* part, int chunks, size_t n_pix, double2* out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pix) return;
+    double re = 0.0, im = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        const double2 v = part[(size_t)c * n_pix + i];
+        re += v.x;
+        im += v.y;
+    }
+    out[i] = make_double2(re, im);
+}
+
+struct Tdbp {
+    int n_p = 0, n_s = 0, nx = 0, ny = 0, taps = 0, m = 0, blk = 0, chunks = 1, per_chunk = 0;
+    sarx_tdbp_params k{};
+    const cf* tw_all = nullptr;
+    cf *hhat = nullptr, *work = nullptr, *rc = nullptr;
+    PulseGeo* geo = nullptr;
+    double *xax = nullptr, *yax = nullptr;
+    double2 *part = nullptr, *img = nullptr;
+    uint64_t bytes = 0;
+};
+
+void tdbp_destroy(Tdbp* t) {
+    if (!t) return;
+    hipFree(t->hhat); hipFree(t->work); hipFree(t->rc); hipFree(t->geo); hipFree(t->xax); hipFree(t->yax);
+    hipFree(t->part); hipFree(t->img);
+    delete t;
+}
+
+#define TCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+Tdbp* tdbp_create(int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp_params* k, const float2* tw_all,
+                  std::string& err) {
+    const int l_ref = (int)(k->t_p * k->fs);                           // int(T_P * FS), :177
+    if (l_ref < 1) { err = "T_P * FS must be >= 1 sample"; return nullptr; }
+    const int taps = l_ref < num_samples ? l_ref : num_samples;       // fft(..., n=num_samples) truncates
+    int m = 16;
+    while (m < num_samples + taps - 1 && m < 32768) m <<= 1;
+    if (m - taps + 1 < m / 2) { err = "reference chirp longer than 16385 samples"; return nullptr; }
+    Tdbp* t = new Tdbp();
+    t->n_p = n_pulses; t->n_s = num_samples; t->nx = nx; t->ny = ny; t->taps = taps; t->m = m; t->blk = m - taps + 1;
+    t->k = *k; t->tw_all = tw_all;
+    const size_t n_pix = (size_t)nx * ny;
+    int chunks = (int)(((size_t)1 << 20) / (n_pix ? n_pix : 1));
+    if (chunks > n_pulses / 32) chunks = n_pulses / 32;
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    t->per_chunk = (n_pulses + chunks - 1) / chunks;
+    t->chunks = (n_pulses + t->per_chunk - 1) / t->per_chunk;
+    auto bail = [&](const char* what, hipError_t e) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        tdbp_destroy(t);
+        return (Tdbp*)nullptr;
+    };
+    // conj(FFT_m(fftshift(ref_chirp))) (:177-179); linspace endpoints as torch builds them (two-sided)
+    std::vector<zd> h(m, zd(0, 0));
+    const double step = l_ref > 1 ? k->t_p / (double)(l_ref - 1) : 0.0;
+    for (int i = 0; i < taps; ++i) {
+        const int src = ((i - l_ref / 2) % l_ref + l_ref) % l_ref;     // fftshift: out[i] = ref[(i - L//2) mod L]
+        const double tt = src < l_ref / 2 ? -k->t_p / 2 + step * (double)src : k->t_p / 2 - step * (double)(l_ref - 1 - src);
+        h[i] = std::polar(1.0, M_PI * k->k_rate * tt * tt);
+    }
+    host_fft_pow2(h);
+    for (auto& v : h) v = std::conj(v);
+    if (m == 32768) to_split_order(h);
+    std::vector<cf> hf(m);
+    for (int i = 0; i < m; ++i) hf[i] = make_float2((float)h[i].real(), (float)h[i].imag());
+    hipError_t e;
+    if ((e = hipMalloc(&t->hhat, (size_t)m * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemcpy(t->hhat, hf.data(), (size_t)m * sizeof(cf), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload", e);
+    if ((e = hipMalloc(&t->work, (size_t)n_pulses * m * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
+    if ((e = hipMalloc(&t->rc, (size_t)n_pulses * num_samples * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&t->geo, (size_t)n_pulses * sizeof(PulseGeo))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&t->xax, (size_t)nx * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&t->yax, (size_t)ny * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&t->part, (size_t)t->chunks * n_pix * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&t->img, n_pix * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
+    t->bytes = (uint64_t)n_pulses * (m + num_samples) * sizeof(cf) + (uint64_t)(t->chunks + 1) * n_pix * sizeof(double2);
+    return t;
+}
+
+// raw: device [n_p][n_s] complex64.  Leaves the range-compressed pulses in t->rc.
+hipError_t tdbp_range_compress(Tdbp* t, const float2* raw, hipStream_t st) {
+    const int n = t->n_s, m = t->m;
+    for (int n0 = 0; n0 < n; n0 += t->blk) {
+        const int cnt = (n - n0 < t->blk) ? n - n0 : t->blk;
+        dim3 grid((m + 255) / 256, t->n_p < 8192 ? t->n_p : 8192);
+        hipLaunchKernelGGL(wrap_copy_kernel, grid, dim3(256), 0, st, raw, t->n_p, n, t->work, m, n0);
+        TCK(hipGetLastError());
+        TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, false, st));
+        TCK(scale_copy_cols(t->work, t->n_p, m, m, t->work, t->n_p, m, m, t->hhat, 1.0f, st));
+        TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, true, st));
+        TCK(scale_copy_cols(t->work, t->n_p, cnt, m, t->rc + n0, t->n_p, cnt, n, nullptr, 1.0f, st));
+    }
+    return hipSuccess;
+}
+
+static void linspace(double a, double b, int n, std::vector<double>& out) {     // numpy.linspace (:173-174)
+    out.resize(n);
+    const double step = n > 1 ? (b - a) / (double)(n - 1) : 0.0;
+    for (int i = 0; i < n; ++i) out[i] = (double)i * step + a;
+    if (n > 1) out[n - 1] = b;
+}
+
+// pos, vel: host [n_p][3]; t_pulses: host [n_p].  Result in t->img (device, complex128 [ny][nx]).
+hipError_t tdbp_backproject(Tdbp* t, const double* pos, const double* vel, const double* t_pulses, double t_start,
+                            const double* vel_focus, double scene_size, hipStream_t st) {
+    std::vector<PulseGeo> geo(t->n_p);
+    double mean = 0.0;
+    for (int p = 0; p < t->n_p; ++p) mean += t_pulses[p];
+    mean /= (double)t->n_p;
+    for (int p = 0; p < t->n_p; ++p) {
+        PulseGeo& g = geo[p];
+        g.px = pos[3 * p]; g.py = pos[3 * p + 1]; g.pz = pos[3 * p + 2];
+        g.wx = vel[3 * p] - vel_focus[0]; g.wy = vel[3 * p + 1] - vel_focus[1]; g.wz = vel[3 * p + 2] - vel_focus[2];
+        g.dt = t_pulses[p] - mean; g.pad = 0.0;
+    }
+    std::vector<double> xa, ya;
+    linspace(-scene_size / 2, scene_size / 2, t->nx, xa);
+    linspace(-scene_size / 2, scene_size / 2, t->ny, ya);
+    // the stream may still be reading the previous call's tables
+    TCK(hipStreamSynchronize(st));
+    TCK(hipMemcpy(t->geo, geo.data(), geo.size() * sizeof(PulseGeo), hipMemcpyHostToDevice));
+    TCK(hipMemcpy(t->xax, xa.data(), xa.size() * sizeof(double), hipMemcpyHostToDevice));
+    TCK(hipMemcpy(t->yax, ya.data(), ya.size() * sizeof(double), hipMemcpyHostToDevice));
+    TdbpArgs a{};
+    a.rc = t->rc; a.geo = t->geo; a.xax = t->xax; a.yax = t->yax; a.part = t->part;
+    a.vfx = vel_focus[0]; a.vfy = vel_focus[1]; a.vfz = vel_focus[2];
+    a.inv_c = 1.0 / t->k.c; a.fc = t->k.fc; a.fs = t->k.fs; a.t_start = t_start;
+    a.k_shift = -t->k.fc * 2.0 / t->k.c / t->k.k_rate;
+    a.inv_ns = 1.0 / (double)t->n_s; a.half_w = (float)t->n_s / 2.0f;
+    a.n_p = t->n_p; a.n_s = t->n_s; a.nx = t->nx; a.ny = t->ny; a.per_chunk = t->per_chunk;
+    const int tiles = ((t->nx + 15) / 16) * ((t->ny + 15) / 16);
+    hipLaunchKernelGGL(tdbp_kernel, dim3(tiles, t->chunks), dim3(256), 0, st, a);
+    TCK(hipGetLastError());
+    const size_t n_pix = (size_t)t->nx * t->ny;
+    hipLaunchKernelGGL(tdbp_reduce_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, st, t->part, t->chunks, n_pix, t->img);
+    return hipGetLastError();
+}
+
+const double2* tdbp_image(const Tdbp* t) { return t->img; }
+const float2* tdbp_rc(const Tdbp* t) { return t->rc; }
+uint64_t tdbp_bytes(const Tdbp* t) { return t->bytes; }
+
+}  // namespace sarx

@@ -34,6 +34,11 @@ class RadarParams(C.Structure):
         "platform_speed_mps", "range_ref_m", "t_start_fast_s")]
 
 
+class TdbpParams(C.Structure):
+    """sarx_tdbp_params: the module constants tdbp_gpu reads (sar_batch_sim.py:13,20,23-25)."""
+    _fields_ = [(n, C.c_double) for n in ("c", "fc", "fs", "t_p", "k_rate")]
+
+
 class AtiOutputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ati_phase", "slc1_mag", "dpca_mag", "ati_interf", "dpca_diff", "slc2_mag", "slc1_phase",
@@ -77,6 +82,11 @@ SIGNATURES = {
     "sarx_multilook_dev": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "sarx_fill_noise_c64": (_i, [_vp, _vp, _sz, _u64]),
     "sarx_echo_synth_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _vp]),
+    "sarx_echo_spotlight_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _vp]),
+    "sarx_tdbp_plan_create": (_i, [_vp, _i, _i, _i, _i, _P(TdbpParams), _P(_vp)]),
+    "sarx_tdbp_plan_destroy": (_i, [_vp]),
+    "sarx_tdbp_focus_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp]),
+    "sarx_tdbp_focus_host": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _vp]),
     "sarx_comm_unique_id": (_i, [_vp]),
     "sarx_comm_init": (_i, [_vp, _vp, _i, _i]),
     "sarx_allgather_dev": (_i, [_vp, _vp, _vp, _sz]),
