@@ -170,6 +170,16 @@ int sarx_multilook_dev(sarx_ctx* ctx, const void* d_in, float* d_out, int rows, 
 /* counter-based N(0,1)+iN(0,1) complex64 noise, reproducible per (seed, index) */
 int sarx_fill_noise_c64(sarx_ctx* ctx, void* d_buf, size_t n, uint64_t seed);
 
+/* thermal noise + K-distributed sea clutter added in place to a complex64 buffer: add_ocean_noise
+ * (sar_satellite_sim.py:331-344) and generate_noise_tensor (sar_batch_sim.py:66-82):
+ * x += noise_std (N + jN) + sqrt(clutter_power * G * E) exp(j 2 pi U), G ~ Gamma(k_nu, 1/k_nu), E ~ Exp(1).
+ * Counter-based (seed, index); clutter_power = 0 skips the clutter. */
+int sarx_add_ocean_noise_dev(sarx_ctx* ctx, void* d_buf, size_t n, double noise_std, double clutter_power, double k_nu,
+                             uint64_t seed);
+/* max and mean of |x|^2 over a complex64 device buffer (blocking): the reference powers of
+ * sar_batch_sim.py:316 (max) and sar_satellite_sim.py:333 (mean).  Either output may be NULL. */
+int sarx_power_stats_dev(sarx_ctx* ctx, const void* d_buf, size_t n, double* max_abs2, double* mean_abs2);
+
 /* ---- point-target echo synthesis: the sample loops of run_physics_engine
  *      (sar_satellite_sim.py:264-302) and run_bistatic_physics_gpu
  *      (sar_ati_dcpa_sim_csa.py:137-178) ---------------------------------------

@@ -75,6 +75,9 @@ hipError_t launch_corner_turn(const float2* in, float2* out, int rows, int cols,
 hipError_t launch_multilook(const float2* in, float* out, int rows, int cols, int looks, hipStream_t st);
 hipError_t launch_fill_noise(float2* buf, size_t n, uint64_t seed, hipStream_t st);
 
+hipError_t launch_ocean_noise(float2* buf, size_t n, float sigma, float clutter_power, float nu, uint64_t seed, hipStream_t st);
+hipError_t launch_power_stats(const float2* buf, size_t n, double* part, int blocks, hipStream_t st);
+
 // echo.hip
 struct EchoArgs {
     const double2* tau_pb;   // [n_pulses][n_targets] {delay s, carrier phase in revolutions}

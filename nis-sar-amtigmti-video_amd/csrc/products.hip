@@ -256,4 +256,103 @@ hipError_t launch_fill_noise(cf* buf, size_t n, uint64_t seed, hipStream_t st) {
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------
+// thermal noise + K-distributed sea clutter added in place (add_ocean_noise, sar_satellite_sim.py:331-344;
+// generate_noise_tensor, sar_batch_sim.py:66-82):
+//   x[i] += sigma (N1 + j N2) + sqrt(Pc * G * E) exp(j 2 pi U),  G ~ Gamma(shape nu, mean 1), E ~ Exp(1)
+// Counter-based: sample i depends only on (seed, i); the Gamma draw is Marsaglia-Tsang with its own counter
+// stream (shape < 1 boosted through Gamma(nu + 1) U^(1/nu)).
+// ------------------------------------------------------------------------------
+struct Rng {
+    uint64_t key, ctr;
+    __device__ __forceinline__ uint64_t next() { return mix64(key + (ctr++) * 0x9E3779B97F4A7C15ull); }
+    __device__ __forceinline__ float uniform() {                       // (0,1)
+        return ((float)(uint32_t)(next() >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    }
+    __device__ __forceinline__ float2 normal2() {
+        const uint64_t h = next();
+        const float u1 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(uint32_t)((h >> 8) & 0xFFFFFF)) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * __logf(u1));
+        float s, c;
+        __sincosf(6.28318530718f * u2, &s, &c);
+        return make_float2(r * c, r * s);
+    }
+};
+__device__ float gamma_unit_mean(Rng& g, float nu) {
+    const float k = nu < 1.0f ? nu + 1.0f : nu;
+    const float d = k - 1.0f / 3.0f, c = rsqrtf(9.0f * d);
+    float out = d;
+    for (int it = 0; it < 64; ++it) {                                  // acceptance > 95 % per round
+        const float x = g.normal2().x;
+        float v = 1.0f + c * x;
+        if (v <= 0.f) continue;
+        v = v * v * v;
+        const float u = g.uniform();
+        if (__logf(u) < 0.5f * x * x + d - d * v + d * __logf(v)) { out = d * v; break; }
+    }
+    if (nu < 1.0f) out *= __powf(g.uniform(), 1.0f / nu);
+    return out / nu;                                                   // scale 1/nu: unit mean
+}
+__global__ __launch_bounds__(256) void ocean_noise_kernel(cf* buf, size_t n, float sigma, float clutter_power, float nu,
+                                                          uint64_t seed) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        Rng g{mix64(seed * 0xD1342543DE82EF95ull + i), 0};
+        const float2 th = g.normal2();
+        cf x = buf[i];
+        x.x += sigma * th.x;
+        x.y += sigma * th.y;
+        if (clutter_power > 0.f) {
+            const float tex = gamma_unit_mean(g, nu);
+            const float spk = -__logf(g.uniform());
+            const float amp = sqrtf(clutter_power * tex * spk);
+            float s, c;
+            __sincosf(6.28318530718f * g.uniform(), &s, &c);
+            x.x += amp * c;
+            x.y += amp * s;
+        }
+        buf[i] = x;
+    }
+}
+hipError_t launch_ocean_noise(cf* buf, size_t n, float sigma, float clutter_power, float nu, uint64_t seed, hipStream_t st) {
+    size_t b = (n + 255) / 256;
+    if (b > 16384) b = 16384;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(ocean_noise_kernel, dim3((unsigned)b), dim3(256), 0, st, buf, n, sigma, clutter_power, nu, seed);
+    return hipGetLastError();
+}
+
+// max and sum of |x|^2 (signal power for the noise level: sar_satellite_sim.py:333, sar_batch_sim.py:316);
+// per-block partials in fp64, finished on the host in block order
+__global__ __launch_bounds__(256) void power_stats_kernel(const cf* buf, size_t n, double* part) {
+    __shared__ double s_sum[256];
+    __shared__ float s_max[256];
+    const size_t stride = (size_t)gridDim.x * 256;
+    double sum = 0.0;
+    float mx = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const cf x = buf[i];
+        const float p = x.x * x.x + x.y * x.y;
+        sum += (double)p;
+        mx = fmaxf(mx, p);
+    }
+    s_sum[threadIdx.x] = sum;
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s_sum[0]; part[2 * blockIdx.x + 1] = (double)s_max[0]; }
+}
+hipError_t launch_power_stats(const cf* buf, size_t n, double* part, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(power_stats_kernel, dim3(blocks), dim3(256), 0, st, buf, n, part);
+    return hipGetLastError();
+}
+
 }  // namespace sarx

@@ -681,6 +681,34 @@ int sarx_fill_noise_c64(sarx_ctx* c, void* buf, size_t n, uint64_t seed) {
     return SARX_OK;
 }
 
+int sarx_add_ocean_noise_dev(sarx_ctx* c, void* buf, size_t n, double noise_std, double clutter_power, double k_nu,
+                             uint64_t seed) {
+    NEED_CTX(c);
+    if (!buf) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (!(noise_std >= 0) || !(clutter_power >= 0) || (clutter_power > 0 && !(k_nu > 0)))
+        return fail(c, SARX_ERR_INVALID, "noise_std, clutter_power must be >= 0 and k_nu > 0");
+    if (n) HIPCHK(c, launch_ocean_noise((float2*)buf, n, (float)noise_std, (float)clutter_power, (float)k_nu, seed, c->stream));
+    return SARX_OK;
+}
+int sarx_power_stats_dev(sarx_ctx* c, const void* buf, size_t n, double* max_abs2, double* mean_abs2) {
+    NEED_CTX(c);
+    if (!buf || !n) return fail(c, SARX_ERR_INVALID, "empty buffer");
+    const int blocks = 1024;
+    double* d_part = nullptr;
+    HIPCHK(c, hipMalloc(&d_part, 2 * blocks * sizeof(double)));
+    hipError_t e = launch_power_stats((const float2*)buf, n, d_part, blocks, c->stream);
+    std::vector<double> part(2 * blocks);
+    if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_part);
+    HIPCHK(c, e);
+    double sum = 0.0, mx = 0.0;
+    for (int b = 0; b < blocks; ++b) { sum += part[2 * b]; if (part[2 * b + 1] > mx) mx = part[2 * b + 1]; }
+    if (max_abs2) *max_abs2 = mx;
+    if (mean_abs2) *mean_abs2 = sum / (double)n;
+    return SARX_OK;
+}
+
 // ---- RCCL ------------------------------------------------------------------------
 int sarx_comm_unique_id(void* id_out) {
     if (!id_out) return fail(nullptr, SARX_ERR_INVALID, "id_out is NULL");

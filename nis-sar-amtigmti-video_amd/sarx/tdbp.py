@@ -159,6 +159,7 @@ class TdbpPlan:
         prm = _ffi.TdbpParams(consts["C"], consts["FC"], consts["FS"], consts["T_P"], consts["K_RATE"])
         self.h = C.c_void_p()
         check(ctx.lib.sarx_tdbp_plan_create(ctx.h, *self.shape, C.byref(prm), C.byref(self.h)), ctx.h)
+        ctx._plans.add(self)          # closed with the context, before sarx_destroy
 
     def focus(self, raw, pos_plat, vel_plat, t_start, vel_focus, t_pulses, scene_size, want_rc=False):
         n_p, n_s, nx, ny = self.shape
@@ -187,9 +188,9 @@ class TdbpPlan:
         return (img, rc) if want_rc else img
 
     def close(self):
-        if self.h:
+        if self.h and self.ctx.h is not None:
             self.ctx.lib.sarx_tdbp_plan_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

@@ -1,0 +1,64 @@
+"""Ocean noise model on the GPU (sar_satellite_sim.py:331-344, sar_batch_sim.py:66-82).  The reference draws
+from unseeded global generators, so there is no sample-level fixture: parity is on the moments the model
+defines (thermal variance, clutter power, K-distribution intensity moments, uniform phase) - "parity unpinned"
+at the sample level, pinned at the distribution level."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(n, ref_power, snr_db, scr_db, k_nu, seed):
+    import sarx
+    ctx = sarx.default_context()
+    d = ctx.to_device(np.zeros(n, dtype=np.complex64))
+    sarx.add_noise_dev(d, n, ref_power, snr_db, scr_db, k_nu, seed)
+    x = d.download(np.complex64, (n,))
+    d.release()
+    return x
+
+
+def test_thermal_only_moments():
+    x = _noise(1 << 20, 4.0, 6.0, None, 1.0, 1)
+    p_n = 4.0 / 10 ** 0.6
+    assert abs(np.mean(np.abs(x) ** 2) / p_n - 1) < 0.01
+    assert abs(np.var(x.real) / (p_n / 2) - 1) < 0.01 and abs(np.var(x.imag) / (p_n / 2) - 1) < 0.01
+    assert abs(np.mean(x)) < 0.01 * np.sqrt(p_n)
+    assert abs(np.mean(np.abs(x) ** 4) / (2 * p_n ** 2) - 1) < 0.03          # complex Gaussian: E|x|^4 = 2 P^2
+
+
+@pytest.mark.parametrize("k_nu", [0.5, 1.0, 4.0])
+def test_k_clutter_moments(k_nu):
+    """intensity I = Pc * G * E: E[I] = Pc, E[I^2] = 2 Pc^2 (1 + 1/nu); thermal made negligible (SNR 80 dB)."""
+    pc = 2.0 / 10 ** 1.0
+    x = _noise(1 << 21, 2.0, 80.0, 10.0, k_nu, 7)
+    i = np.abs(x.astype(np.complex128)) ** 2
+    assert abs(np.mean(i) / pc - 1) < 0.02
+    assert abs(np.mean(i ** 2) / (2 * pc ** 2 * (1 + 1 / k_nu)) - 1) < 0.08
+    ph = np.angle(x)
+    assert abs(np.mean(np.exp(1j * ph))) < 0.005
+
+
+def test_reproducible_and_seeded():
+    a = _noise(4096, 1.0, 10.0, 10.0, 1.0, 3)
+    assert np.array_equal(a, _noise(4096, 1.0, 10.0, 10.0, 1.0, 3))
+    assert not np.array_equal(a, _noise(4096, 1.0, 10.0, 10.0, 1.0, 4))
+
+
+def test_add_ocean_noise_and_power_stats():
+    import sarx
+    rng = np.random.default_rng(0)
+    raw = (rng.standard_normal((64, 512)) + 1j * rng.standard_normal((64, 512))).astype(np.complex64) * 3
+    ctx = sarx.default_context()
+    d = ctx.to_device(raw)
+    mx, mean = sarx.power_stats(d, raw.size)
+    d.release()
+    p = np.abs(raw.astype(np.complex128)) ** 2
+    assert abs(mx / p.max() - 1) < 1e-6 and abs(mean / p.mean() - 1) < 1e-6
+    out = sarx.add_ocean_noise(raw, 3.0, seed=5)
+    assert out.shape == raw.shape and out.dtype == np.complex64
+    added = np.mean(np.abs(out - raw) ** 2)
+    want = p.mean() / 10 ** 0.3 + p.mean() / 10 ** 1.0
+    assert abs(added / want - 1) < 0.05
+    snr, gain = sarx.calculate_snr_db(509e3, 50000.0, 0.031, 500e6, 1.2)
+    assert np.isfinite(snr) and abs(gain - 10 * np.log10(4 * np.pi * 3.5 * 0.5 * 0.6 / 0.031 ** 2)) < 1e-9
