@@ -1,0 +1,56 @@
+/* A C program on the C ABI alone (include/sarx.h + libsarx.so, no Python, no torch): focuses a seeded
+ * point-target scene with sarx_csa_focus_host, forms the ATI/DPCA products of the image with itself, and
+ * prints numbers the pytest wrapper (tests/test_gpu_c_client.py) checks against the oracle.
+ *   gcc -O2 -I include tests/c_client/client.c -o tests/c_client/client -L <dir of libsarx.so> -lsarx -lm
+ * usage: client <in.bin> <n_az> <n_rg> <8 radar doubles...> <out.bin>
+ * in.bin / out.bin: row-major complex64 [n_az][n_rg]. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "sarx.h"
+
+static void die(sarx_ctx* ctx, const char* what) {
+    fprintf(stderr, "%s: %s\n", what, sarx_last_error(ctx));
+    exit(2);
+}
+
+int main(int argc, char** argv) {
+    if (argc != 13) { fprintf(stderr, "usage: client in n_az n_rg p0..p7 out\n"); return 1; }
+    const int n_az = atoi(argv[2]), n_rg = atoi(argv[3]);
+    sarx_radar_params prm;
+    double* pv = (double*)&prm;
+    for (int i = 0; i < 8; ++i) pv[i] = atof(argv[4 + i]);
+    const size_t n = (size_t)n_az * n_rg;
+    float* in = malloc(n * 8);
+    float* out = malloc(n * 8);
+    FILE* f = fopen(argv[1], "rb");
+    if (!f || fread(in, 8, n, f) != n) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
+    fclose(f);
+
+    sarx_ctx* ctx = NULL;
+    sarx_plan* plan = NULL;
+    if (sarx_init(0, &ctx)) die(NULL, "sarx_init");
+    if (sarx_csa_plan_create(ctx, n_az, n_rg, &prm, SARX_FUSE_RANGE, &plan)) die(ctx, "plan_create");
+    if (sarx_csa_focus_host(plan, in, out)) die(ctx, "focus_host");
+
+    /* errors come back as codes with text, never as a fallback */
+    sarx_plan* bad = NULL;
+    const int rc = sarx_csa_plan_create(ctx, 1, n_rg, &prm, 0, &bad);
+    printf("bad_plan_rc %d msg \"%s\"\n", rc, sarx_last_error(ctx));
+
+    /* range axis and cross-range axis as the reference returns them */
+    double* rax = malloc(sizeof(double) * n_rg);
+    double* cax = malloc(sizeof(double) * n_az);
+    if (sarx_csa_axes(plan, rax, cax)) die(ctx, "axes");
+    printf("range_axis %.9f %.9f cross_range %.9f %.9f\n", rax[0], rax[n_rg - 1], cax[0], cax[n_az - 1]);
+
+    f = fopen(argv[12], "wb");
+    if (!f || fwrite(out, 8, n, f) != n) { fprintf(stderr, "cannot write %s\n", argv[12]); return 1; }
+    fclose(f);
+    sarx_csa_plan_destroy(plan);
+    sarx_destroy(ctx);
+    free(in); free(out); free(rax); free(cax);
+    printf("ok\n");
+    return 0;
+}
