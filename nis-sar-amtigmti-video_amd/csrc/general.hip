@@ -277,15 +277,100 @@ template <int WHICH> static hipError_t phase(GeneralCsa* g, cf* d, hipStream_t s
     return hipGetLastError();
 }
 
+// ---- fused hand-over between two transforms ---------------------------------------------------------
+// out[r][c] = in[r][c] * row_vec[r] * col_vec[c] * scale * Phi_WHICH(r, c)   for r < n_az, c < n_rg, else 0
+// The post-chirp of the Bluestein transform that just finished, the CSA phase, and the pre-chirp / zero padding of
+// the next transform in ONE pass (three before).  in may equal out when the leading dimensions agree.
+struct BridgeArgs {
+    const cf* in; size_t in_ld;
+    cf* out; size_t out_ld;
+    int n_az, n_rg, out_rows, out_cols;
+    const cf *row_vec, *col_vec;
+    float scale;
+    const double2* c;
+    double dt, t_start, t0, df;
+};
+template <int WHICH> __global__ __launch_bounds__(256) void bridge_kernel(BridgeArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.out_cols) return;
+    const bool cin = j < a.n_rg;
+    const double tau = __dadd_rn(a.t_start, __dmul_rn((double)j, a.dt));
+    const int ks = (j < (a.n_rg + 1) / 2) ? j : j - a.n_rg;            // numpy.fft.fftfreq order, any parity
+    const double f = (double)ks * a.df;
+    cf cv = make_float2(a.scale, 0.f);
+    if (a.col_vec && cin) { const cf w = a.col_vec[j]; cv = make_float2(w.x * a.scale, w.y * a.scale); }
+    for (int i = blockIdx.y; i < a.out_rows; i += gridDim.y) {
+        cf x = make_float2(0.f, 0.f);
+        if (cin && i < a.n_az) {
+            const double2 c = a.c[i];
+            double p;
+            if (WHICH == 1) { const double d = tau - c.y; p = c.x * d * d; }                          // :272
+            else if (WHICH == 2) p = f * fma(c.x, f, c.y);                                            // :318-324
+            else { const double d = tau - a.t0; p = fma(c.x, tau, c.y * d * d); }                     // :359,375-380
+            x = cmul(cmul(a.in[(size_t)i * a.in_ld + j], cv), cis_rev(p));
+            if (a.row_vec) x = cmul(x, a.row_vec[i]);
+        }
+        a.out[(size_t)i * a.out_ld + j] = x;
+    }
+}
+template <int WHICH>
+static hipError_t bridge(GeneralCsa* g, const cf* in, size_t in_ld, cf* out, size_t out_ld, int out_rows, int out_cols,
+                         const cf* row_vec, const cf* col_vec, float scale, hipStream_t st) {
+    BridgeArgs a{};
+    a.in = in; a.in_ld = in_ld; a.out = out; a.out_ld = out_ld;
+    a.n_az = g->n_az; a.n_rg = g->n_rg; a.out_rows = out_rows; a.out_cols = out_cols;
+    a.row_vec = row_vec; a.col_vec = col_vec; a.scale = scale;
+    a.c = (WHICH == 1) ? g->c1 : (WHICH == 2) ? g->c2 : g->c3;
+    a.dt = 1.0 / g->p.sample_rate_hz; a.t_start = g->p.t_start_fast_s;
+    a.t0 = 2.0 * g->p.range_ref_m / 299792458.0;
+    a.df = 1.0 / ((double)g->n_rg * a.dt);
+    dim3 grid((out_cols + 255) / 256, out_rows < 16384 ? out_rows : 16384);
+    hipLaunchKernelGGL(bridge_kernel<WHICH>, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// column transform of x [m_az x ldc] (already chirped and padded when the axis is not direct) into y, x is scratch
+static hipError_t cols_core(GeneralCsa* g, cf* x, cf* y, bool inv, hipStream_t st) {
+    const Axis& ax = g->az;
+    if (ax.direct) return cols_pow2(g, x, x, y, g->n_az, g->ldc, inv, st);
+    GCK(cols_pow2(g, x, x, y, ax.m, g->ldc, false, st));
+    GCK(scale_copy(y, ax.m, g->ldc, g->ldc, x, ax.m, g->ldc, g->ldc, inv ? ax.bhat_i : ax.bhat_f, nullptr, 1.0f, st));
+    return cols_pow2(g, x, x, y, ax.m, g->ldc, true, st);
+}
+// line transform in place on w [n_az x m_rg] (chirped and padded when the axis is not direct)
+static hipError_t rows_core(GeneralCsa* g, cf* w, bool inv, hipStream_t st) {
+    const Axis& ax = g->rg;
+    if (ax.direct) return rows_pow2(g, w, g->n_az, g->n_rg, inv, st);
+    GCK(rows_pow2(g, w, g->n_az, ax.m, false, st));
+    GCK(scale_copy(w, g->n_az, ax.m, ax.m, w, g->n_az, ax.m, ax.m, nullptr, inv ? ax.bhat_i : ax.bhat_f, 1.0f, st));
+    return rows_pow2(g, w, g->n_az, ax.m, true, st);
+}
+
+// sar_focus_csa (:233-385) at any size.  Buffers: wa/wb [m_az x ldc] for the column transforms, work_a doubles as
+// the [n_az x m_rg] line-transform array when the range axis is not a power of two (else the dense image `data`).
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st) {
-    cf* d = g->data;
-    GCK(fft_cols(g, d_in, d, false, st));          // :233
-    GCK(phase<1>(g, d, st));                       // :272-274
-    GCK(fft_rows(g, d, false, st));                // :278
-    GCK(phase<2>(g, d, st));                       // :318-326
-    GCK(fft_rows(g, d, true, st));                 // :331
-    GCK(phase<3>(g, d, st));                       // :359-382
-    return fft_cols(g, d, d_out, true, st);        // :385
+    const Axis &az = g->az, &rg = g->rg;
+    const int n_az = g->n_az, n_rg = g->n_rg, ld = g->ldc;
+    cf *wa = g->work_a, *wb = g->work_b;
+    cf* lines = rg.direct ? g->data : g->work_a;            // where the range transforms run
+    const size_t lines_ld = rg.direct ? (size_t)n_rg : (size_t)rg.m;
+    const int lines_cols = rg.direct ? n_rg : rg.m;
+    // azimuth FFT (:233): d_in -> wa (chirp, pad) -> wb
+    GCK(scale_copy(d_in, n_az, n_rg, n_rg, wa, az.m, ld, ld, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
+    GCK(cols_core(g, wa, wb, false, st));
+    // * azimuth post-chirp * Phi_1 (:272-274) * range pre-chirp, into the line array
+    GCK(bridge<1>(g, wb, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, rg.direct ? nullptr : rg.chirp_f,
+                  1.0f, st));
+    GCK(rows_core(g, lines, false, st));                                              // :278
+    // post-chirp of the forward and pre-chirp of the inverse are conjugates: only Phi_2 (:318-326) and the zero padding remain
+    GCK(bridge<2>(g, lines, lines_ld, lines, lines_ld, n_az, lines_cols, nullptr, nullptr, 1.0f, st));
+    GCK(rows_core(g, lines, true, st));                                               // :331
+    // * range post-chirp / n_rg * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a may hold the lines)
+    GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, rg.direct ? nullptr : rg.chirp_i,
+                  rg.direct ? 1.0f : 1.0f / (float)n_rg, st));
+    GCK(cols_core(g, wb, wa, true, st));                                              // :385
+    return scale_copy(wa, n_az, n_rg, ld, d_out, n_az, n_rg, n_rg, nullptr, nullptr, az.direct ? 1.0f : 1.0f / (float)n_az, st, 0,
+                      az.direct ? nullptr : az.chirp_i);
 }
 
 // =====================================================================================================
