@@ -9,7 +9,8 @@ namespace sarx {
 enum RangeMode { RG_FFT = 0, RG_IFFT = 1, RG_FFT_PHI2 = 2, RG_IFFT_PHI3 = 3, RG_FUSED = 4 };
 enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_SCALE = 3,
                   AZ_EPI_TWCOL = 4,      // * W_M^(col*m_out), M = 1/tw_scale (32768-point line split, forward)
-                  AZ_EPI_PROCOL = 5 };   // inputs * W_M^(col*m_in) first, outputs * scale (its inverse)
+                  AZ_EPI_PROCOL = 5,     // inputs * W_M^(col*m_in) first, outputs * scale (its inverse)
+                  AZ_EPI_ROWVEC = 6 };   // * rowvec[output row] (Bluestein filter spectrum fused into the forward transform)
 
 struct RangeArgs {
     const float2* in;
@@ -23,6 +24,8 @@ struct RangeArgs {
     double t0;            // 2 R_ref / c
     float inv_n;          // 1/n_rg
     int n_az;
+    const float2* mulvec; // RG_FFT only, optional: out[line][k] *= mulvec[(line % mul_period) * n_rg + k]
+    int mul_period;
 };
 
 struct AzArgs {
@@ -31,6 +34,7 @@ struct AzArgs {
     const float2* tw_r;   // exp(-2 pi i m / R), m < R      (in-tile FFT)
     const float2* tw_n;   // exp(-2 pi i m / n_az), m < n_az (four-step twiddle)
     const double2* c1;    // per azimuth bin: {-0.5 Kr Cs, tau_ref}
+    const float2* rowvec; // AZ_EPI_ROWVEC: per output row
     double dt, t_start;
     float scale;          // 1/n_az for the inverse's last step
     float tw_scale;       // 1/M for the column-indexed twiddles of the 32768-point line split

@@ -50,6 +50,17 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
         constexpr int RL = E::R_last;
         if constexpr (MODE == RG_FFT) {
             if (live) {
+                if (a.mulvec) {       // spectrum of the Bluestein filter fused into the forward transform (general.hip)
+                    const cf* __restrict__ mv = a.mulvec + (size_t)(row % a.mul_period) * N;
+#pragma unroll
+                    for (int b = 0; b < P / RL; ++b)
+#pragma unroll
+                        for (int r = 0; r < RL; ++r) {
+                            const int k = E::out_index(t, b, r);
+                            dst[k] = cmul(v[b * RL + r], mv[k]);
+                        }
+                    return;
+                }
 #pragma unroll
                 for (int b = 0; b < P / RL; ++b)
 #pragma unroll
@@ -228,6 +239,8 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                 x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
             } else if constexpr (EPI == AZ_EPI_SCALE || EPI == AZ_EPI_PROCOL) {
                 x.x *= a.scale; x.y *= a.scale;
+            } else if constexpr (EPI == AZ_EPI_ROWVEC) {
+                x = cmul(x, a.rowvec[rowo]);
             } else if constexpr (EPI == AZ_EPI_TWCOL) {    // 32768-point line as 128 x 256: twiddle W_M^(+-col*m)
                 const float rev = (float)(col * m) * a.tw_scale;
                 x = cmul(x, cis_frac(INV ? rev : -rev));
@@ -249,6 +262,7 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_TWIDDLE: return launch_az_one<R, W, false, AZ_EPI_TWIDDLE>(a, nq, st);
             case AZ_EPI_PHI1: return launch_az_one<R, W, false, AZ_EPI_PHI1>(a, nq, st);
             case AZ_EPI_TWCOL: return launch_az_one<R, W, false, AZ_EPI_TWCOL>(a, nq, st);
+            case AZ_EPI_ROWVEC: return launch_az_one<R, W, false, AZ_EPI_ROWVEC>(a, nq, st);
         }
     } else {
         switch (epi) {

@@ -17,7 +17,9 @@ uint64_t general_csa_bytes(const GeneralCsa* g);
 // building blocks shared with tdbp.hip
 // in-place line FFTs of `rows` contiguous lines of length m (power of two, 16..32768); the inverse carries 1/m.
 // m == 32768 leaves the spectrum in the split order of to_split_order(); the inverse expects that order.
-hipError_t line_fft_pow2(const float2* tw_all, float2* buf, int rows, int m, bool inv, hipStream_t st);
+// mulvec (forward only, optional): the spectrum is multiplied by mulvec[k] (device order) in the transform's epilogue
+hipError_t line_fft_pow2(const float2* tw_all, float2* buf, int rows, int m, bool inv, hipStream_t st,
+                         const float2* mulvec = nullptr);
 void host_fft_pow2(std::vector<std::complex<double>>& a);         // forward, in place
 void to_split_order(std::vector<std::complex<double>>& a);        // 32768-point spectrum: natural -> device order
 // out[r][c] = (r < in_rows && c < in_cols ? in[r][c] : 0) * colvec[c] * scalar   (colvec optional)

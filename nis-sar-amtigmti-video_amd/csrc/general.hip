@@ -166,11 +166,13 @@ struct GeneralCsa {
 };
 
 // ---- power-of-two transforms on work arrays ---------------------------------------------------------
-static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, hipStream_t st) {
+// mulvec (forward only): the m-point spectrum is multiplied by mulvec[k] (device order at 32768) on the way out
+static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, hipStream_t st, const cf* mulvec = nullptr) {
     RangeArgs a{};
     hipError_t e;
     if (m <= 16384) {
         a.in = buf; a.out = buf; a.tw = g->tw_all + m; a.inv_n = 1.0f / (float)m; a.n_az = rows;
+        a.mulvec = inv ? nullptr : mulvec; a.mul_period = 1;
         return launch_range_pass(m, inv ? RG_IFFT : RG_FFT, a, st);
     }
     // 32768 = 128 x 256 on the [(rows*128) x 256] view of the lines
@@ -181,6 +183,7 @@ static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, h
     a.in = buf; a.out = buf; a.tw = g->tw_all + SPLIT_B; a.inv_n = 1.0f / (float)SPLIT_B; a.n_az = rows * SPLIT_A;
     if (!inv) {
         if ((e = launch_az_tile(SPLIT_A, 32, false, AZ_EPI_TWCOL, z, rows, st)) != hipSuccess) return e;
+        a.mulvec = mulvec; a.mul_period = SPLIT_A;          // line L = row*128 + k1 holds positions k1*256 + k2
         return launch_range_pass(SPLIT_B, RG_FFT, a, st);
     }
     if ((e = launch_range_pass(SPLIT_B, RG_IFFT, a, st)) != hipSuccess) return e;
@@ -188,7 +191,8 @@ static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, h
 }
 
 // column FFT of length n (power of two, 16..16384) on a [n x ld] array, ld a multiple of 32; in -> out via tmp
-static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n, int ld, bool inv, hipStream_t st) {
+static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n, int ld, bool inv, hipStream_t st,
+                            const cf* rowvec = nullptr) {
     int l2 = 0;
     while ((1 << l2) < n) ++l2;
     const int S = (n <= 128) ? n : (1 << (l2 / 2)), RA = n / S;
@@ -196,7 +200,8 @@ static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n
     a.scale = 1.0f / (float)n;
     a.n_rg = ld;
     a.tw_n = g->tw_all + n;
-    const int epi_last = inv ? AZ_EPI_SCALE : AZ_EPI_NONE;
+    const int epi_last = inv ? AZ_EPI_SCALE : (rowvec ? AZ_EPI_ROWVEC : AZ_EPI_NONE);
+    a.rowvec = rowvec;
     if (S == n) {
         a.in = in; a.out = out; a.tw_r = g->tw_all + n;
         a.in_q_stride = 0; a.in_m_stride = 1; a.out_q_stride = 0; a.out_m_stride = 1;
@@ -211,10 +216,10 @@ static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n
     return launch_az_tile(S, 32, inv, epi_last, a, RA, st);
 }
 
-hipError_t line_fft_pow2(const float2* tw_all, float2* buf, int rows, int m, bool inv, hipStream_t st) {
+hipError_t line_fft_pow2(const float2* tw_all, float2* buf, int rows, int m, bool inv, hipStream_t st, const float2* mulvec) {
     GeneralCsa g;
     g.tw_all = tw_all;
-    return rows_pow2(&g, buf, rows, m, inv, st);
+    return rows_pow2(&g, buf, rows, m, inv, st, mulvec);
 }
 void host_fft_pow2(std::vector<zd>& a) { host_fft(a); }
 void to_split_order(std::vector<zd>& a) {
@@ -329,20 +334,20 @@ static hipError_t bridge(GeneralCsa* g, const cf* in, size_t in_ld, cf* out, siz
     return hipGetLastError();
 }
 
-// column transform of x [m_az x ldc] (already chirped and padded when the axis is not direct) into y, x is scratch
-static hipError_t cols_core(GeneralCsa* g, cf* x, cf* y, bool inv, hipStream_t st) {
+// column transform of x [m_az x ldc] (already chirped and padded when the axis is not direct); x and y are both
+// overwritten; returns the buffer holding the result through *res
+static hipError_t cols_core(GeneralCsa* g, cf* x, cf* y, bool inv, hipStream_t st, cf** res) {
     const Axis& ax = g->az;
-    if (ax.direct) return cols_pow2(g, x, x, y, g->n_az, g->ldc, inv, st);
-    GCK(cols_pow2(g, x, x, y, ax.m, g->ldc, false, st));
-    GCK(scale_copy(y, ax.m, g->ldc, g->ldc, x, ax.m, g->ldc, g->ldc, inv ? ax.bhat_i : ax.bhat_f, nullptr, 1.0f, st));
-    return cols_pow2(g, x, x, y, ax.m, g->ldc, true, st);
+    if (ax.direct) { *res = y; return cols_pow2(g, x, x, y, g->n_az, g->ldc, inv, st); }
+    *res = x;
+    GCK(cols_pow2(g, x, x, y, ax.m, g->ldc, false, st, inv ? ax.bhat_i : ax.bhat_f));     // * filter spectrum in the epilogue
+    return cols_pow2(g, y, y, x, ax.m, g->ldc, true, st);
 }
 // line transform in place on w [n_az x m_rg] (chirped and padded when the axis is not direct)
 static hipError_t rows_core(GeneralCsa* g, cf* w, bool inv, hipStream_t st) {
     const Axis& ax = g->rg;
     if (ax.direct) return rows_pow2(g, w, g->n_az, g->n_rg, inv, st);
-    GCK(rows_pow2(g, w, g->n_az, ax.m, false, st));
-    GCK(scale_copy(w, g->n_az, ax.m, ax.m, w, g->n_az, ax.m, ax.m, nullptr, inv ? ax.bhat_i : ax.bhat_f, 1.0f, st));
+    GCK(rows_pow2(g, w, g->n_az, ax.m, false, st, inv ? ax.bhat_i : ax.bhat_f));         // * filter spectrum in the epilogue
     return rows_pow2(g, w, g->n_az, ax.m, true, st);
 }
 
@@ -355,11 +360,13 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
     cf* lines = rg.direct ? g->data : g->work_a;            // where the range transforms run
     const size_t lines_ld = rg.direct ? (size_t)n_rg : (size_t)rg.m;
     const int lines_cols = rg.direct ? n_rg : rg.m;
-    // azimuth FFT (:233): d_in -> wa (chirp, pad) -> wb
-    GCK(scale_copy(d_in, n_az, n_rg, n_rg, wa, az.m, ld, ld, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
-    GCK(cols_core(g, wa, wb, false, st));
+    // azimuth FFT (:233): d_in -> (chirp, pad) -> wb
+    // (the result must land in wb: work_a may become the line array next)
+    cf *first = az.direct ? wa : wb, *other = az.direct ? wb : wa, *res = nullptr;
+    GCK(scale_copy(d_in, n_az, n_rg, n_rg, first, az.m, ld, ld, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
+    GCK(cols_core(g, first, other, false, st, &res));
     // * azimuth post-chirp * Phi_1 (:272-274) * range pre-chirp, into the line array
-    GCK(bridge<1>(g, wb, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, rg.direct ? nullptr : rg.chirp_f,
+    GCK(bridge<1>(g, res, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, rg.direct ? nullptr : rg.chirp_f,
                   1.0f, st));
     GCK(rows_core(g, lines, false, st));                                              // :278
     // post-chirp of the forward and pre-chirp of the inverse are conjugates: only Phi_2 (:318-326) and the zero padding remain
@@ -368,8 +375,8 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
     // * range post-chirp / n_rg * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a may hold the lines)
     GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, rg.direct ? nullptr : rg.chirp_i,
                   rg.direct ? 1.0f : 1.0f / (float)n_rg, st));
-    GCK(cols_core(g, wb, wa, true, st));                                              // :385
-    return scale_copy(wa, n_az, n_rg, ld, d_out, n_az, n_rg, n_rg, nullptr, nullptr, az.direct ? 1.0f : 1.0f / (float)n_az, st, 0,
+    GCK(cols_core(g, wb, wa, true, st, &res));                                        // :385
+    return scale_copy(res, n_az, n_rg, ld, d_out, n_az, n_rg, n_rg, nullptr, nullptr, az.direct ? 1.0f : 1.0f / (float)n_az, st, 0,
                       az.direct ? nullptr : az.chirp_i);
 }
 
@@ -543,8 +550,7 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st) {
     cf* w = g->work_a;
     // 1 range compression
     GCK(scale_copy(d_in, n_p, n_r, n_r, w, n_p, m, m, nullptr, nullptr, 1.0f, st));
-    GCK(rows_pow2(g, w, n_p, m, false, st));
-    GCK(scale_copy(w, n_p, m, m, w, n_p, m, m, nullptr, r->hhat, 1.0f, st));
+    GCK(rows_pow2(g, w, n_p, m, false, st, r->hhat));            // * filter spectrum in the epilogue
     GCK(rows_pow2(g, w, n_p, m, true, st));
     GCK(scale_copy(w + (r->l_mf - 1) / 2, n_p, n_r, m, r->pc, n_p, n_r, n_r, nullptr, nullptr, 1.0f, st));   // mode='same'
     // 2 window, fftshift . FFT . fftshift over pulses: roll by h = n_p/2 is source row (r - h) mod n

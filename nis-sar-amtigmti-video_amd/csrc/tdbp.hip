@@ -183,8 +183,7 @@ hipError_t tdbp_range_compress(Tdbp* t, const float2* raw, hipStream_t st) {
         dim3 grid((m + 255) / 256, t->n_p < 8192 ? t->n_p : 8192);
         hipLaunchKernelGGL(wrap_copy_kernel, grid, dim3(256), 0, st, raw, t->n_p, n, t->work, m, n0);
         TCK(hipGetLastError());
-        TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, false, st));
-        TCK(scale_copy_cols(t->work, t->n_p, m, m, t->work, t->n_p, m, m, t->hhat, 1.0f, st));
+        TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, false, st, t->hhat));      // * conj(reference spectrum) in the epilogue
         TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, true, st));
         TCK(scale_copy_cols(t->work, t->n_p, cnt, m, t->rc + n0, t->n_p, cnt, n, nullptr, 1.0f, st));
     }
