@@ -52,6 +52,7 @@ def main():
         for algo, focus_tgt in (("mBP", True), ("StdBP", False)):     # :283-286
             run_id = f"{v['name']}_{int(v['speed'])}_{int(h)}_{algo}"
             frames = []
+            d_raw = None
             t0 = time.time()
             for f in range(NUM_FRAMES):
                 i0 = f * STEP_PULSES
@@ -60,7 +61,8 @@ def main():
                     break
                 t_cpi, p_cpi, v_cpi = t_vec_all[i0:i1], pos_sat_all[i0:i1], vel_sat_all[i0:i1]
                 d_raw, t_st, n_sp, v_tgt = sarx.run_physics_spotlight(base_target, t_cpi, p_cpi, v_cpi, heading_deg=h,
-                                                                      speed=v["speed"], l_ant=L_ANT, consts=k, device=True)
+                                                                      speed=v["speed"], l_ant=L_ANT, consts=k, device=True,
+                                                                      out=d_raw)   # one pulse buffer for all frames
                 n = len(t_cpi) * n_sp
                 sig_p, _ = sarx.power_stats(d_raw, n)                                          # :313 max |raw|^2
                 sarx.add_noise_dev(d_raw, n, sig_p, snr_db_raw + k["SNR_BOOST_DB"], k["SCR_DB"], k["K_NU"],
@@ -68,8 +70,9 @@ def main():
                 vf = v_tgt if focus_tgt else np.zeros(3)
                 img = sarx.tdbp_gpu(d_raw, p_cpi, v_cpi, t_st, n_sp, vel_focus=vf, t_pulses=t_cpi,
                                     scene_size=v["swath"], nx=a.nx, ny=a.nx, consts=k)        # :318-321
-                d_raw.release()
                 frames.append(img.astype(np.complex64))
+            if d_raw is not None:
+                d_raw.release()
             ctx.sync()
             dt = time.time() - t0
             stack = np.stack(frames)

@@ -93,10 +93,11 @@ def spotlight_window(consts=None):
 
 
 def run_physics_spotlight(base_targets, t_vec, pos_sat, vel_sat, heading_deg, speed, l_ant, *, consts=None, ctx=None,
-                          device=False):
+                          device=False, out=None):
     """Spotlight echo of a rigid target moving at ``speed`` along ``heading_deg``; drop-in for
     sar_batch_sim.py:85-169.  returns (raw [len(t_vec) x num_samples] complex64, t_start, num_samples, v_tgt).
-    ``device=True`` leaves raw on the GPU (a DeviceBuffer) for ``tdbp_gpu``."""
+    ``device=True`` leaves raw on the GPU (a DeviceBuffer) for ``tdbp_gpu``; ``out`` (implies device) is a
+    DeviceBuffer of at least len(t_vec) * num_samples * 8 bytes to fill instead of allocating one per call."""
     k = consts or batch_constants()
     Cc, FC, T_P, K_RATE, Lambda = k["C"], k["FC"], k["T_P"], k["K_RATE"], k["Lambda"]
     ctx = ctx or default_context()
@@ -112,22 +113,27 @@ def run_physics_spotlight(base_targets, t_vec, pos_sat, vel_sat, heading_deg, sp
     vel_sat = np.asarray(vel_sat, dtype=np.float64)
     n_pulses, n_tgt = t_vec.size, p0.shape[0]
     d_tf = ctx.to_device(np.ascontiguousarray(t_fast_abs))
-    d_raw = ctx.alloc(n_pulses * num_samples * 8)
+    if out is not None:
+        if out.nbytes < n_pulses * num_samples * 8:
+            raise ValueError("out buffer too small")
+        d_raw, device = out, True
+    else:
+        d_raw = ctx.alloc(n_pulses * num_samples * 8)
     step = max(1, min(_PULSE_CHUNK, (64 << 20) // max(24 * n_tgt, 1)))
     for i0 in range(0, n_pulses, step):
         i1 = min(i0 + step, n_pulses)
         ps = pos_sat[i0:i1, None, :]
         p_tgt = p0[None, :, :] + v_tgt[None, None, :] * t_vec[i0:i1, None, None]                   # :127
         diff_tx = p_tgt - ps
-        dist_tx = np.linalg.norm(diff_tx, axis=2)
+        dist_tx = _norm3(diff_tx)
         tau_approx = 2 * dist_tx / Cc
         p_rx = ps + vel_sat[i0:i1, None, :] * tau_approx[:, :, None]                               # :131
-        dist_rx = np.linalg.norm(p_tgt - p_rx, axis=2)
+        dist_rx = _norm3(p_tgt - p_rx)
         tau = (dist_tx + dist_rx) / Cc
         b_vec = -ps                                                                                # p_center = 0
-        look = b_vec / np.linalg.norm(b_vec, axis=2, keepdims=True)
-        tgt_vec = diff_tx / dist_tx[:, :, None]
-        angle_off = np.arccos(np.clip(np.sum(look * tgt_vec, axis=2), -1, 1))                      # :138-139
+        look = b_vec / _norm3(b_vec)[:, :, None]
+        cos_off = (look[..., 0] * diff_tx[..., 0] + look[..., 1] * diff_tx[..., 1] + look[..., 2] * diff_tx[..., 2]) / dist_tx
+        angle_off = np.arccos(np.clip(cos_off, -1, 1))                                             # :136-139
         x_val = np.pi * l_ant * np.sin(angle_off) / Lambda
         gain = np.ones_like(x_val)
         m = np.abs(x_val) > 1e-6
@@ -148,6 +154,11 @@ def run_physics_spotlight(base_targets, t_vec, pos_sat, vel_sat, heading_deg, sp
     raw = d_raw.download(np.complex64, (n_pulses, num_samples))
     d_raw.release()
     return raw, t_start, num_samples, v_tgt
+
+
+def _norm3(v):
+    """Euclidean norm over a last axis of length 3 (np.linalg.norm reduces short axes slowly)."""
+    return np.sqrt(v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1] + v[..., 2] * v[..., 2])
 
 
 class TdbpPlan:
