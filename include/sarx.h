@@ -220,6 +220,11 @@ int sarx_tdbp_focus_host(sarx_tdbp_plan* plan, const void* raw_host, const doubl
                          const double* t_pulses, double t_start, const double* vel_focus, double scene_size,
                          void* image_host, void* range_compressed_host);
 
+/* Only the samples of each pulse that the scene can touch are range-compressed (a bound from the geometry: the
+ * back-projection of a 500 m scene reads ~1700 of 22004 samples); asking for range_compressed_host compresses all.
+ * [*lo, *hi) of the last focus call, for inspection. */
+int sarx_tdbp_last_window(const sarx_tdbp_plan* plan, int* lo, int* hi);
+
 /* ---- multi-GPU: RCCL all-gather of the image stack over xGMI ------------- */
 #define SARX_COMM_ID_BYTES 128
 int sarx_comm_unique_id(void* id_out /*[SARX_COMM_ID_BYTES]*/);

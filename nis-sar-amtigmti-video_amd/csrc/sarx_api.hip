@@ -651,9 +651,13 @@ int sarx_tdbp_focus_dev(sarx_tdbp_plan* p, const void* d_raw, const double* pos,
     hipSetDevice(c->device);
     if (!d_raw || !pos || !vel || !t_pulses || !vel_focus || !d_image) return fail(c, SARX_ERR_INVALID, "NULL pointer");
     if (!(scene_size > 0)) return fail(c, SARX_ERR_INVALID, "scene_size must be positive");
-    HIPCHK(c, tdbp_range_compress(p->t, (const float2*)d_raw, c->stream));
-    HIPCHK(c, tdbp_backproject(p->t, pos, vel, t_pulses, t_start, vel_focus, scene_size, c->stream));
+    HIPCHK(c, tdbp_focus(p->t, (const float2*)d_raw, pos, vel, t_pulses, t_start, vel_focus, scene_size, false, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_image, tdbp_image(p->t), (size_t)p->nx * p->ny * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    return SARX_OK;
+}
+int sarx_tdbp_last_window(const sarx_tdbp_plan* p, int* lo, int* hi) {
+    if (!p || !lo || !hi) return fail(nullptr, SARX_ERR_INVALID, "NULL argument");
+    tdbp_window(p->t, lo, hi);
     return SARX_OK;
 }
 int sarx_tdbp_focus_host(sarx_tdbp_plan* p, const void* raw, const double* pos, const double* vel, const double* t_pulses,
@@ -666,8 +670,7 @@ int sarx_tdbp_focus_host(sarx_tdbp_plan* p, const void* raw, const double* pos, 
     const size_t n = (size_t)p->n_p * p->n_s;
     if (!p->d_raw) HIPCHK(c, hipMalloc(&p->d_raw, n * sizeof(float2)));
     HIPCHK(c, hipMemcpyAsync(p->d_raw, raw, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, tdbp_range_compress(p->t, p->d_raw, c->stream));
-    HIPCHK(c, tdbp_backproject(p->t, pos, vel, t_pulses, t_start, vel_focus, scene_size, c->stream));
+    HIPCHK(c, tdbp_focus(p->t, p->d_raw, pos, vel, t_pulses, t_start, vel_focus, scene_size, range_compressed != nullptr, c->stream));
     HIPCHK(c, hipMemcpyAsync(image, tdbp_image(p->t), (size_t)p->nx * p->ny * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
     if (range_compressed) HIPCHK(c, hipMemcpyAsync(range_compressed, tdbp_rc(p->t), n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

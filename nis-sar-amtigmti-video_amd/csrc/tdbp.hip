@@ -18,6 +18,8 @@
 
 #include <cmath>
 #include <complex>
+#include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "fft_core.hpp"
@@ -109,7 +111,11 @@ struct Tdbp {
     int n_p = 0, n_s = 0, nx = 0, ny = 0, taps = 0, m = 0, blk = 0, chunks = 1, per_chunk = 0;
     sarx_tdbp_params k{};
     const cf* tw_all = nullptr;
-    cf *hhat = nullptr, *work = nullptr, *rc = nullptr;
+    cf *work = nullptr, *rc = nullptr;
+    std::map<int, cf*> hhat;      // conj spectrum of the reference chirp per FFT length (device order)
+    int l_ref = 0;
+    bool full_rc = false;         // SARX_TDBP_FULL_RC=1: always compress every sample
+    int win_lo = 0, win_hi = 0;   // samples compressed by the last call
     PulseGeo* geo = nullptr;
     double *xax = nullptr, *yax = nullptr;
     double2 *part = nullptr, *img = nullptr;
@@ -118,12 +124,41 @@ struct Tdbp {
 
 void tdbp_destroy(Tdbp* t) {
     if (!t) return;
-    hipFree(t->hhat); hipFree(t->work); hipFree(t->rc); hipFree(t->geo); hipFree(t->xax); hipFree(t->yax);
+    for (auto& kv : t->hhat) hipFree(kv.second);
+    hipFree(t->work); hipFree(t->rc); hipFree(t->geo); hipFree(t->xax); hipFree(t->yax);
     hipFree(t->part); hipFree(t->img);
     delete t;
 }
 
 #define TCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+// conj(FFT_m(fftshift(ref_chirp))) (:177-179) for an m-point transform, cached; linspace endpoints as torch builds
+// them (two-sided)
+static hipError_t filter_spectrum(Tdbp* t, int m, cf** out) {
+    auto it = t->hhat.find(m);
+    if (it != t->hhat.end()) { if (out) *out = it->second; return hipSuccess; }
+    const int l_ref = t->l_ref;
+    const sarx_tdbp_params* k = &t->k;
+    std::vector<zd> h(m, zd(0, 0));
+    const double step = l_ref > 1 ? k->t_p / (double)(l_ref - 1) : 0.0;
+    for (int i = 0; i < t->taps; ++i) {
+        const int src = ((i - l_ref / 2) % l_ref + l_ref) % l_ref;     // fftshift: out[i] = ref[(i - L//2) mod L]
+        const double tt = src < l_ref / 2 ? -k->t_p / 2 + step * (double)src : k->t_p / 2 - step * (double)(l_ref - 1 - src);
+        h[i] = std::polar(1.0, M_PI * k->k_rate * tt * tt);
+    }
+    host_fft_pow2(h);
+    for (auto& v : h) v = std::conj(v);
+    if (m == 32768) to_split_order(h);
+    std::vector<cf> hf(m);
+    for (int i = 0; i < m; ++i) hf[i] = make_float2((float)h[i].real(), (float)h[i].imag());
+    cf* d = nullptr;
+    TCK(hipMalloc(&d, (size_t)m * sizeof(cf)));
+    hipError_t e = hipMemcpy(d, hf.data(), (size_t)m * sizeof(cf), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(d); return e; }
+    t->hhat[m] = d;
+    if (out) *out = d;
+    return hipSuccess;
+}
 
 Tdbp* tdbp_create(int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp_params* k, const float2* tw_all,
                   std::string& err) {
@@ -148,22 +183,10 @@ Tdbp* tdbp_create(int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp
         tdbp_destroy(t);
         return (Tdbp*)nullptr;
     };
-    // conj(FFT_m(fftshift(ref_chirp))) (:177-179); linspace endpoints as torch builds them (two-sided)
-    std::vector<zd> h(m, zd(0, 0));
-    const double step = l_ref > 1 ? k->t_p / (double)(l_ref - 1) : 0.0;
-    for (int i = 0; i < taps; ++i) {
-        const int src = ((i - l_ref / 2) % l_ref + l_ref) % l_ref;     // fftshift: out[i] = ref[(i - L//2) mod L]
-        const double tt = src < l_ref / 2 ? -k->t_p / 2 + step * (double)src : k->t_p / 2 - step * (double)(l_ref - 1 - src);
-        h[i] = std::polar(1.0, M_PI * k->k_rate * tt * tt);
-    }
-    host_fft_pow2(h);
-    for (auto& v : h) v = std::conj(v);
-    if (m == 32768) to_split_order(h);
-    std::vector<cf> hf(m);
-    for (int i = 0; i < m; ++i) hf[i] = make_float2((float)h[i].real(), (float)h[i].imag());
     hipError_t e;
-    if ((e = hipMalloc(&t->hhat, (size_t)m * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemcpy(t->hhat, hf.data(), (size_t)m * sizeof(cf), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload", e);
+    t->l_ref = l_ref;
+    if (const char* ev = getenv("SARX_TDBP_FULL_RC")) t->full_rc = atoi(ev) != 0;
+    if ((e = filter_spectrum(t, m, nullptr)) != hipSuccess) return bail("filter spectrum", e);
     if ((e = hipMalloc(&t->work, (size_t)n_pulses * m * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
     if ((e = hipMalloc(&t->rc, (size_t)n_pulses * num_samples * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&t->geo, (size_t)n_pulses * sizeof(PulseGeo))) != hipSuccess) return bail("hipMalloc", e);
@@ -175,19 +198,62 @@ Tdbp* tdbp_create(int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp
     return t;
 }
 
-// raw: device [n_p][n_s] complex64.  Leaves the range-compressed pulses in t->rc.
-hipError_t tdbp_range_compress(Tdbp* t, const float2* raw, hipStream_t st) {
-    const int n = t->n_s, m = t->m;
-    for (int n0 = 0; n0 < n; n0 += t->blk) {
-        const int cnt = (n - n0 < t->blk) ? n - n0 : t->blk;
-        dim3 grid((m + 255) / 256, t->n_p < 8192 ? t->n_p : 8192);
-        hipLaunchKernelGGL(wrap_copy_kernel, grid, dim3(256), 0, st, raw, t->n_p, n, t->work, m, n0);
-        TCK(hipGetLastError());
-        TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, false, st, t->hhat));      // * conj(reference spectrum) in the epilogue
-        TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, true, st));
-        TCK(scale_copy_cols(t->work, t->n_p, cnt, m, t->rc + n0, t->n_p, cnt, n, nullptr, 1.0f, st));
+// outputs [n0, n0 + cnt) of the circular correlation through one m-point transform (cnt <= m - taps + 1)
+static hipError_t compress_block(Tdbp* t, const float2* raw, int n0, int cnt, int m, hipStream_t st) {
+    cf* hhat = nullptr;
+    TCK(filter_spectrum(t, m, &hhat));
+    const int n = t->n_s;
+    dim3 grid((m + 255) / 256, t->n_p < 8192 ? t->n_p : 8192);
+    hipLaunchKernelGGL(wrap_copy_kernel, grid, dim3(256), 0, st, raw, t->n_p, n, t->work, m, n0);
+    TCK(hipGetLastError());
+    TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, false, st, hhat));      // * conj(reference spectrum) in the epilogue
+    TCK(line_fft_pow2(t->tw_all, t->work, t->n_p, m, true, st));
+    return scale_copy_cols(t->work, t->n_p, cnt, m, t->rc + n0, t->n_p, cnt, n, nullptr, 1.0f, st);
+}
+
+// raw: device [n_p][n_s] complex64.  Leaves the range-compressed samples [lo, hi) of every pulse in t->rc
+// (the back-projection of one scene reads a narrow window of each pulse: ~1700 of 22004 samples natively).
+hipError_t tdbp_range_compress(Tdbp* t, const float2* raw, int lo, int hi, hipStream_t st) {
+    const int n = t->n_s;
+    if (lo < 0) lo = 0;
+    if (hi > n) hi = n;
+    t->win_lo = lo; t->win_hi = hi;
+    if (hi <= lo) return hipSuccess;
+    int m = 16;
+    while (m < (hi - lo) + t->taps - 1) m <<= 1;
+    if (m < t->m) return compress_block(t, raw, lo, hi - lo, m, st);        // one transform shorter than the plan's
+    for (int n0 = lo; n0 < hi; n0 += t->blk) {
+        const int cnt = (hi - n0 < t->blk) ? hi - n0 : t->blk;
+        TCK(compress_block(t, raw, n0, cnt, t->m, st));
     }
     return hipSuccess;
+}
+
+// Sample window [lo, hi) that the back-projection can touch: a bound, not an estimate.  Per pulse the pixel rectangle
+// moved by v_f dt is convex, so the transmit range is largest at a corner and smallest at the projection of the
+// platform clamped to the rectangle; |d_rx - d_tx| <= |v_rel| tau_a and |t_shift| <= |v_rel| |k_shift| (:209-219).
+static void sample_window(const Tdbp* t, const std::vector<PulseGeo>& geo, const double* vf, double t_start, double scene_size,
+                          int* lo, int* hi) {
+    const double c = t->k.c, fs = t->k.fs, ks = fabs(t->k.fc * 2.0 / t->k.c / t->k.k_rate), h = scene_size / 2;
+    double imin = 1e300, imax = -1e300;
+    for (const PulseGeo& g : geo) {
+        const double sx = vf[0] * g.dt, sy = vf[1] * g.dt, gz = vf[2] * g.dt - g.pz;
+        const double qx = g.px - sx, qy = g.py - sy;                    // platform relative to the moved rectangle
+        const double cx = qx < -h ? -h : (qx > h ? h : qx), cy = qy < -h ? -h : (qy > h ? h : qy);
+        const double dmin = sqrt((cx - qx) * (cx - qx) + (cy - qy) * (cy - qy) + gz * gz);
+        const double ax = fabs(qx) + h, ay = fabs(qy) + h;              // farthest corner
+        const double dmax = sqrt(ax * ax + ay * ay + gz * gz);
+        const double w = sqrt(g.wx * g.wx + g.wy * g.wy + g.wz * g.wz);
+        const double slack = w * (2.0 * dmax / c);
+        const double a = ((2.0 * dmin - slack) / c - t_start - w * ks) * fs;
+        const double b = ((2.0 * dmax + slack) / c - t_start + w * ks) * fs;
+        if (a < imin) imin = a;
+        if (b > imax) imax = b;
+    }
+    // x = idx - 0.5 rounded through float32 (< 1 sample at any n_s <= 2^23), i0 = floor(x), i0 + 1 is read too
+    const double l = floor(imin) - 3.0, u = ceil(imax) + 4.0;
+    *lo = l < 0 ? 0 : (l > (double)t->n_s ? t->n_s : (int)l);
+    *hi = u < 0 ? 0 : (u > (double)t->n_s ? t->n_s : (int)u);
 }
 
 static void linspace(double a, double b, int n, std::vector<double>& out) {     // numpy.linspace (:173-174)
@@ -197,9 +263,10 @@ static void linspace(double a, double b, int n, std::vector<double>& out) {     
     if (n > 1) out[n - 1] = b;
 }
 
-// pos, vel: host [n_p][3]; t_pulses: host [n_p].  Result in t->img (device, complex128 [ny][nx]).
-hipError_t tdbp_backproject(Tdbp* t, const double* pos, const double* vel, const double* t_pulses, double t_start,
-                            const double* vel_focus, double scene_size, hipStream_t st) {
+// raw: device [n_p][n_s]; pos, vel: host [n_p][3]; t_pulses: host [n_p].  Result in t->img (device, complex128 [ny][nx]).
+// all_samples: compress every sample of every pulse (the caller wants rc_data), else only the window the scene can touch
+hipError_t tdbp_focus(Tdbp* t, const float2* raw, const double* pos, const double* vel, const double* t_pulses, double t_start,
+                      const double* vel_focus, double scene_size, bool all_samples, hipStream_t st) {
     std::vector<PulseGeo> geo(t->n_p);
     double mean = 0.0;
     for (int p = 0; p < t->n_p; ++p) mean += t_pulses[p];
@@ -213,6 +280,9 @@ hipError_t tdbp_backproject(Tdbp* t, const double* pos, const double* vel, const
     std::vector<double> xa, ya;
     linspace(-scene_size / 2, scene_size / 2, t->nx, xa);
     linspace(-scene_size / 2, scene_size / 2, t->ny, ya);
+    int lo = 0, hi = t->n_s;
+    if (!all_samples && !t->full_rc) sample_window(t, geo, vel_focus, t_start, scene_size, &lo, &hi);
+    TCK(tdbp_range_compress(t, raw, lo, hi, st));
     // the stream may still be reading the previous call's tables
     TCK(hipStreamSynchronize(st));
     TCK(hipMemcpy(t->geo, geo.data(), geo.size() * sizeof(PulseGeo), hipMemcpyHostToDevice));
@@ -235,6 +305,7 @@ hipError_t tdbp_backproject(Tdbp* t, const double* pos, const double* vel, const
 
 const double2* tdbp_image(const Tdbp* t) { return t->img; }
 const float2* tdbp_rc(const Tdbp* t) { return t->rc; }
+void tdbp_window(const Tdbp* t, int* lo, int* hi) { *lo = t->win_lo; *hi = t->win_hi; }
 uint64_t tdbp_bytes(const Tdbp* t) { return t->bytes; }
 
 }  // namespace sarx

@@ -87,6 +87,7 @@ SIGNATURES = {
     "sarx_echo_spotlight_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _vp]),
     "sarx_tdbp_plan_create": (_i, [_vp, _i, _i, _i, _i, _P(TdbpParams), _P(_vp)]),
     "sarx_tdbp_plan_destroy": (_i, [_vp]),
+    "sarx_tdbp_last_window": (_i, [_vp, _vp, _vp]),
     "sarx_tdbp_focus_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp]),
     "sarx_tdbp_focus_host": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _vp]),
     "sarx_comm_unique_id": (_i, [_vp]),

@@ -198,6 +198,12 @@ class TdbpPlan:
                                        rc.ctypes.data if want_rc else None), ctx.h)
         return (img, rc) if want_rc else img
 
+    def last_window(self):
+        """[lo, hi) samples of each pulse that the last focus call range-compressed."""
+        lo, hi = C.c_int(), C.c_int()
+        check(self.ctx.lib.sarx_tdbp_last_window(self.h, C.byref(lo), C.byref(hi)), self.ctx.h)
+        return lo.value, hi.value
+
     def close(self):
         if self.h and self.ctx.h is not None:
             self.ctx.lib.sarx_tdbp_plan_destroy(self.h)

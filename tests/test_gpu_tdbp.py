@@ -66,6 +66,27 @@ def test_tdbp_native_pulse_length_two_blocks():
     assert rel_l2(img, ref) < TOL
 
 
+def test_windowed_compression_equals_full():
+    """Only the samples the scene can touch are compressed (a geometric bound); the image equals the one from
+    fully compressed pulses (forced by asking for rc_data), and the native window is a small part of the pulse."""
+    import sarx
+    k = tb.batch_constants()
+    sc = tb.tdbp_scene(n_pulses=40, seed=4, k=k, speed=15.0, heading_deg=120.0, swath=500.0, n_targets=4)
+    raw = sc["raw"].astype(np.complex64)
+    plan = sarx.TdbpPlan(sarx.default_context(), 40, sc["num_samples"], 32, 32, k)
+    args = (sc["pos"], sc["vel"], sc["t_start"], sc["v_tgt"], sc["t_vec"], sc["swath"])
+    win = plan.focus(raw, *args)
+    lo, hi = plan.last_window()
+    full, rc = plan.focus(raw, *args, want_rc=True)
+    assert plan.last_window() == (0, sc["num_samples"])
+    plan.close()
+    assert 0 < lo < hi < sc["num_samples"] and hi - lo < 2500
+    assert rel_l2(win, full) < 1e-5
+    # every sample the reference's interpolation reads lies inside the window: outside it the pulse energy is irrelevant
+    ref = tb.tdbp(raw, sc["pos"], sc["vel"], sc["t_start"], sc["num_samples"], sc["v_tgt"], sc["t_vec"], sc["swath"], 32, 32, k)
+    assert rel_l2(win, ref) < TOL
+
+
 def test_device_resident_chain_and_chunking():
     """run_physics_spotlight(device=True) -> tdbp_gpu without a host round trip equals the host-buffer chain;
     160 pulses x 40 x 40 pixels exercises several pulse chunks."""
