@@ -190,6 +190,16 @@ int sarx_echo_synth_dev(sarx_ctx* ctx, const double* d_tau_pb, const float* d_am
                         int n_pulses, int n_targets, int n_samples, double chirp_rate_hz_s, double pulse_width_s,
                         void* d_raw);
 
+/* Per pulse and target geometry of the three echo models on the device (fp64): fills the d_tau_pb table (and, for
+ * model 2, d_amp_pt) that the sample kernels consume.  All pointers are device pointers.
+ *   model 0: run_physics_engine (sar_satellite_sim.py:268-272)          needs d_tgt_pos, d_tx_pos
+ *   model 1: run_bistatic_physics_gpu (sar_ati_dcpa_sim_csa.py:151-160)  + d_tgt_vel[3], d_t_pulse, d_aux = receiver positions
+ *   model 2: run_physics_spotlight (sar_batch_sim.py:127-150)           + d_aux = platform velocities, d_rcs, l_ant, wavelength */
+int sarx_echo_geometry_dev(sarx_ctx* ctx, int model, int n_pulses, int n_targets, const double* d_tgt_pos,
+                           const double* d_tgt_vel, const double* d_t_pulse, const double* d_tx_pos, const double* d_aux,
+                           const double* d_rcs, double c_light, double fc, double l_ant, double wavelength,
+                           double* d_tau_pb, float* d_amp_pt);
+
 /* run_physics_spotlight (sar_batch_sim.py:85-169), sample loop :145-149: as above with u = t_fast[j]-tau[i][b]
  * (no Tp/2 offset) and an amplitude per pulse and target, d_amp_pt [n_pulses][n_targets] float = rcs * antenna gain */
 int sarx_echo_spotlight_dev(sarx_ctx* ctx, const double* d_tau_pb, const float* d_amp_pt, const double* d_t_fast,

@@ -93,5 +93,19 @@ struct EchoArgs {
     int n_pulses, n_targets, n_samples;
 };
 hipError_t launch_echo_synth(const EchoArgs& a, hipStream_t st);
+struct EchoGeoArgs {
+    int model;                // 0 monostatic, 1 bistatic, 2 spotlight
+    int n_pulses, n_targets;
+    const double* tgt_pos;    // [n_targets][3] at t = 0
+    const double* tgt_vel;    // [3] common target velocity (models 1, 2)
+    const double* t_pulse;    // [n_pulses] slow time (models 1, 2)
+    const double* tx_pos;     // [n_pulses][3] transmitter / platform position
+    const double* aux;        // [n_pulses][3]: receiver position (model 1) or platform velocity (model 2)
+    const double* rcs;        // [n_targets] (model 2)
+    double c, fc, l_ant, lambda;
+    double2* tau_pb;          // out [n_pulses][n_targets]
+    float* amp_pt;            // out [n_pulses][n_targets] (model 2)
+};
+hipError_t launch_echo_geometry(const EchoGeoArgs& a, hipStream_t st);
 
 }  // namespace sarx

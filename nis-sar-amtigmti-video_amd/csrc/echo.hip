@@ -52,6 +52,59 @@ __global__ __launch_bounds__(ECHO_THREADS) void echo_synth_kernel(EchoArgs a) {
     if (live) a.out[(size_t)i * a.n_samples + j] = make_float2(acc_re, acc_im);
 }
 
+// ------------------------------------------------------------------------------
+// Per pulse and target geometry on the device (fp64, the reference's formulas): delay tau, carrier phase in
+// revolutions, and for the spotlight model the amplitude rcs * sinc^2 antenna gain.  The reference does this part in
+// NumPy / torch on [pulses x targets x 3] arrays (36 M pairs and 0.9 GB per clutter call of the two-channel script);
+// here it is one small launch whose table the sample kernel above consumes without a host round trip.
+//   model 0  run_physics_engine        (sar_satellite_sim.py:268-272): tau = 2 d / C, pb = -2 FC d / C
+//   model 1  run_bistatic_physics_gpu  (sar_ati_dcpa_sim_csa.py:151-160): targets move, tau = (d_tx + d_rx) / C, pb = -FC tau
+//   model 2  run_physics_spotlight     (sar_batch_sim.py:127-150): receiver displaced by v_sat * 2 d_tx / C, antenna gain
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void echo_geometry_kernel(EchoGeoArgs a) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (b >= a.n_targets) return;
+    const double t = a.t_pulse ? a.t_pulse[i] : 0.0;
+    double px = a.tgt_pos[3 * b], py = a.tgt_pos[3 * b + 1], pz = a.tgt_pos[3 * b + 2];
+    if (a.model != 0) { px += a.tgt_vel[0] * t; py += a.tgt_vel[1] * t; pz += a.tgt_vel[2] * t; }
+    const double sx = a.tx_pos[3 * i], sy = a.tx_pos[3 * i + 1], sz = a.tx_pos[3 * i + 2];
+    const double dx = px - sx, dy = py - sy, dz = pz - sz;
+    const double d_tx = sqrt(dx * dx + dy * dy + dz * dz);
+    double tau, pb;
+    if (a.model == 0) {
+        tau = 2.0 * d_tx / a.c;
+        pb = -2.0 * a.fc * d_tx / a.c;
+    } else if (a.model == 1) {
+        const double ex = px - a.aux[3 * i], ey = py - a.aux[3 * i + 1], ez = pz - a.aux[3 * i + 2];   // aux = receiver position
+        const double d_rx = sqrt(ex * ex + ey * ey + ez * ez);
+        tau = (d_tx + d_rx) / a.c;
+        pb = -a.fc * tau;
+    } else {
+        const double tau_a = 2.0 * d_tx / a.c;                                                      // aux = platform velocity
+        const double rx = sx + a.aux[3 * i] * tau_a, ry = sy + a.aux[3 * i + 1] * tau_a, rz = sz + a.aux[3 * i + 2] * tau_a;
+        const double ex = px - rx, ey = py - ry, ez = pz - rz;
+        const double d_rx = sqrt(ex * ex + ey * ey + ez * ez);
+        tau = (d_tx + d_rx) / a.c;
+        pb = -a.fc * tau;
+        // look direction: scene centre (origin) seen from the platform (:134-139)
+        const double bn = sqrt(sx * sx + sy * sy + sz * sz);
+        double cos_off = ((-sx / bn) * (dx / d_tx) + (-sy / bn) * (dy / d_tx) + (-sz / bn) * (dz / d_tx));
+        cos_off = cos_off < -1.0 ? -1.0 : (cos_off > 1.0 ? 1.0 : cos_off);
+        const double x = M_PI * a.l_ant * sin(acos(cos_off)) / a.lambda;                           // :140
+        double gain = 1.0;
+        if (fabs(x) > 1e-6) { const double q = sin(x) / x; gain = q * q; }                        // :141-144
+        a.amp_pt[(size_t)i * a.n_targets + b] = (float)(a.rcs[b] * gain);                          // :150
+    }
+    a.tau_pb[(size_t)i * a.n_targets + b] = make_double2(tau, pb);
+}
+
+hipError_t launch_echo_geometry(const EchoGeoArgs& a, hipStream_t st) {
+    dim3 grid((a.n_targets + 255) / 256, a.n_pulses);
+    hipLaunchKernelGGL(echo_geometry_kernel, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_echo_synth(const EchoArgs& a, hipStream_t st) {
     dim3 grid((a.n_samples + ECHO_THREADS - 1) / ECHO_THREADS, a.n_pulses);
     hipLaunchKernelGGL(echo_synth_kernel, grid, dim3(ECHO_THREADS), 0, st, a);

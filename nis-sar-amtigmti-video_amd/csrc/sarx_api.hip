@@ -597,6 +597,24 @@ int sarx_echo_synth_dev(sarx_ctx* c, const double* tau_pb, const float* amp, con
     HIPCHK(c, launch_echo_synth(a, c->stream));
     return SARX_OK;
 }
+int sarx_echo_geometry_dev(sarx_ctx* c, int model, int n_pulses, int n_targets, const double* tgt_pos, const double* tgt_vel,
+                           const double* t_pulse, const double* tx_pos, const double* aux, const double* rcs, double c_light,
+                           double fc, double l_ant, double wavelength, double* tau_pb, float* amp_pt) {
+    NEED_CTX(c);
+    if (model < 0 || model > 2) return fail(c, SARX_ERR_INVALID, "echo model must be 0, 1 or 2");
+    if (n_pulses <= 0 || n_targets <= 0 || n_pulses > 65535) return fail(c, SARX_ERR_INVALID, "echo sizes must be positive (n_pulses <= 65535 per call)");
+    if (!tgt_pos || !tx_pos || !tau_pb) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (model != 0 && (!tgt_vel || !t_pulse || !aux)) return fail(c, SARX_ERR_INVALID, "models 1 and 2 need target velocity, pulse times and aux");
+    if (model == 2 && (!rcs || !amp_pt || !(wavelength > 0))) return fail(c, SARX_ERR_INVALID, "model 2 needs rcs, amp_pt and the wavelength");
+    if (!(c_light > 0) || !(fc > 0)) return fail(c, SARX_ERR_INVALID, "C and FC must be positive");
+    EchoGeoArgs a{};
+    a.model = model; a.n_pulses = n_pulses; a.n_targets = n_targets;
+    a.tgt_pos = tgt_pos; a.tgt_vel = tgt_vel; a.t_pulse = t_pulse; a.tx_pos = tx_pos; a.aux = aux; a.rcs = rcs;
+    a.c = c_light; a.fc = fc; a.l_ant = l_ant; a.lambda = wavelength;
+    a.tau_pb = (double2*)tau_pb; a.amp_pt = amp_pt;
+    HIPCHK(c, launch_echo_geometry(a, c->stream));
+    return SARX_OK;
+}
 int sarx_echo_spotlight_dev(sarx_ctx* c, const double* tau_pb, const float* amp_pt, const double* t_fast, int n_pulses,
                             int n_targets, int n_samples, double kr, double t_p, void* raw) {
     NEED_CTX(c);

@@ -2,9 +2,10 @@
 
 The reference keeps its radar constants as module globals; here they are keyword
 arguments that default to the same values (sarx.radar.reference_constants()).
-Geometry per pulse and target (ranges, delays, carrier phase) is NumPy fp64 on the
-host exactly as the reference computes it; the n_pulses x n_targets x n_samples
-sample loop - the reference's real wall-clock sink - runs in one HIP kernel.
+Geometry per pulse and target (ranges, delays, carrier phase: fp64, the reference's
+formulas) and the n_pulses x n_targets x n_samples sample loop - the reference's
+real wall-clock sink - both run in HIP kernels; the host only uploads targets and
+the per-pulse platform state.
 Returns complex64 (the reference returns complex128; the focuser computes in complex64).
 """
 from __future__ import annotations
@@ -12,31 +13,58 @@ from __future__ import annotations
 import numpy as np
 
 from . import radar
+from ._ffi import check
 from .engine import default_context
 
-_PULSE_CHUNK = 4096          # bounds the [pulses x targets] fp64 table sent per launch
+_PULSE_CHUNK = 4096          # bounds the [pulses x targets] fp64 table held on the device per launch
 
 
-def _synth(ctx, tau, pb_rev, amp, t_fast_abs, kr, t_p):
-    n_pulses, n_tgt = tau.shape
-    n_samp = t_fast_abs.size
-    d_amp = ctx.to_device(np.ascontiguousarray(amp, dtype=np.float32))
+def synth_device(ctx, model, tgt_pos, tgt_vel, t_pulse, tx_pos, aux, amp_or_rcs, t_fast_abs, kr, t_p, c_light, fc,
+                 l_ant=0.0, wavelength=0.0, out=None):
+    """Geometry kernel + sample kernel, pulse chunk by pulse chunk, entirely on the device.
+    model 0/1: amp_or_rcs = sqrt(rcs) per target; model 2 (spotlight): rcs per target (the gain is per pulse).
+    Returns the DeviceBuffer holding raw [n_pulses x n_samples] complex64 (``out`` if given)."""
+    lib = ctx.lib
+    n_pulses, n_tgt, n_samp = tx_pos.shape[0], tgt_pos.shape[0], t_fast_abs.size
+    d_tp = ctx.to_device(np.ascontiguousarray(tgt_pos, dtype=np.float64))
+    d_tv = ctx.to_device(np.ascontiguousarray(tgt_vel, dtype=np.float64)) if tgt_vel is not None else None
+    d_t = ctx.to_device(np.ascontiguousarray(t_pulse, dtype=np.float64)) if t_pulse is not None else None
+    d_tx = ctx.to_device(np.ascontiguousarray(tx_pos, dtype=np.float64))
+    d_aux = ctx.to_device(np.ascontiguousarray(aux, dtype=np.float64)) if aux is not None else None
     d_tf = ctx.to_device(np.ascontiguousarray(t_fast_abs, dtype=np.float64))
-    out = np.empty((n_pulses, n_samp), dtype=np.complex64)
-    step = max(1, min(_PULSE_CHUNK, (256 << 20) // max(16 * n_tgt, 1)))
+    if model == 2:
+        d_rcs = ctx.to_device(np.ascontiguousarray(amp_or_rcs, dtype=np.float64))
+        d_amp = None
+    else:
+        d_rcs = None
+        d_amp = ctx.to_device(np.ascontiguousarray(amp_or_rcs, dtype=np.float32))
+    d_raw = out if out is not None else ctx.alloc(n_pulses * n_samp * 8)
+    if d_raw.nbytes < n_pulses * n_samp * 8:
+        raise ValueError("out buffer too small")
+    step = max(1, min(_PULSE_CHUNK, n_pulses, (512 << 20) // max(20 * n_tgt, 1)))
+    d_tab = ctx.alloc(step * n_tgt * 16)
+    d_apt = ctx.alloc(step * n_tgt * 4) if model == 2 else None
+    ptr = lambda b, off=0: (b.ptr + off) if b is not None else None
     for i0 in range(0, n_pulses, step):
-        i1 = min(i0 + step, n_pulses)
-        tp = np.empty((i1 - i0, n_tgt, 2), dtype=np.float64)
-        tp[..., 0] = tau[i0:i1]
-        tp[..., 1] = pb_rev[i0:i1]
-        d_tp = ctx.to_device(tp)
-        d_raw = ctx.alloc((i1 - i0) * n_samp * 8)
-        ctx.echo_synth(d_tp, d_amp, d_tf, i1 - i0, n_tgt, n_samp, kr, t_p, d_raw)
-        out[i0:i1] = d_raw.download(np.complex64, (i1 - i0, n_samp))
-        d_tp.release()
-        d_raw.release()
-    d_amp.release()
-    d_tf.release()
+        n = min(step, n_pulses - i0)
+        check(lib.sarx_echo_geometry_dev(ctx.h, model, n, n_tgt, d_tp.ptr, ptr(d_tv), ptr(d_t, i0 * 8), d_tx.ptr + i0 * 24,
+                                         ptr(d_aux, i0 * 24), ptr(d_rcs), float(c_light), float(fc), float(l_ant),
+                                         float(wavelength), d_tab.ptr, ptr(d_apt)), ctx.h)
+        dst = d_raw.ptr + i0 * n_samp * 8
+        if model == 2:
+            check(lib.sarx_echo_spotlight_dev(ctx.h, d_tab.ptr, d_apt.ptr, d_tf.ptr, n, n_tgt, n_samp, float(kr), float(t_p), dst), ctx.h)
+        else:
+            check(lib.sarx_echo_synth_dev(ctx.h, d_tab.ptr, d_amp.ptr, d_tf.ptr, n, n_tgt, n_samp, float(kr), float(t_p), dst), ctx.h)
+    ctx.sync()
+    for b in (d_tp, d_tv, d_t, d_tx, d_aux, d_tf, d_rcs, d_amp, d_tab, d_apt):
+        if b is not None:
+            b.release()
+    return d_raw
+
+
+def _download(d_raw, shape):
+    out = d_raw.download(np.complex64, shape)
+    d_raw.release()
     return out
 
 
@@ -55,11 +83,9 @@ def run_physics_engine(targets, pos_sat, t_vec, *, BW=None, T_p=None, R0=None, C
     t_pos = np.array([t["position"] for t in targets], dtype=np.float64)
     amp = np.sqrt(np.array([t["rcs"] for t in targets], dtype=np.float64))
     pos_sat = np.asarray(pos_sat, dtype=np.float64)[: len(t_vec)]
-    diff = t_pos[None, :, :] - pos_sat[:, None, :]
-    dist = np.sqrt(np.sum(diff ** 2, axis=2))                       # :268-269
-    tau = 2 * dist / C                                              # :271
-    pb_rev = -2.0 * FC * dist / C                                   # :272 (-4 pi FC d / C) / (2 pi)
-    return _synth(ctx, tau, pb_rev, amp, t_fast_abs, k_rate, T_p), t_start_fast, fs
+    # ranges, delays tau = 2 d / C and carrier phase -4 pi FC d / C (:268-272) per pulse and target: geometry kernel
+    d_raw = synth_device(ctx, 0, t_pos, None, None, pos_sat, None, amp, t_fast_abs, k_rate, T_p, C, FC)
+    return _download(d_raw, (pos_sat.shape[0], num_samples)), t_start_fast, fs
 
 
 def run_bistatic_physics_gpu(targets, t_vec, pos_tx_np, vel_tx_np, rx_offset_dist, vel_target_np, *, FS=None,
@@ -81,9 +107,7 @@ def run_bistatic_physics_gpu(targets, t_vec, pos_tx_np, vel_tx_np, rx_offset_dis
     v_tx = np.asarray(vel_tx_np, dtype=np.float64)
     v_dir = v_tx / np.linalg.norm(v_tx, axis=1, keepdims=True)      # :145
     p_rx = p_tx + v_dir * rx_offset_dist                             # :148
-    p_now = p0[None, :, :] + np.asarray(vel_target_np, dtype=np.float64)[None, None, :] * t_vec[:, None, None]   # :151
-    d_tx = np.linalg.norm(p_now - p_tx[:, None, :], axis=2)         # :156
-    d_rx = np.linalg.norm(p_now - p_rx[:, None, :], axis=2)         # :157
-    tau = (d_tx + d_rx) / C                                         # :159
-    pb_rev = -FC * tau                                              # :160 (-2 pi FC tau) / (2 pi)
-    return _synth(ctx, tau, pb_rev, amp, t_fast_abs, k_rate, T_p), t_start_fast
+    # target motion p0 + v t (:151), d_tx, d_rx (:156-157), tau = (d_tx + d_rx) / C, phase -2 pi FC tau (:159-160): geometry kernel
+    d_raw = synth_device(ctx, 1, p0, np.asarray(vel_target_np, dtype=np.float64), t_vec, p_tx, p_rx, amp, t_fast_abs, k_rate, T_p,
+                         C, FC)
+    return _download(d_raw, (t_vec.size, num_samples)), t_start_fast

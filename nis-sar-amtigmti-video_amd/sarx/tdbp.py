@@ -4,8 +4,7 @@
 
 The reference functions read module globals; here they are the keyword argument ``consts`` (a dict with the
 reference's names C, FC, FS, T_P, K_RATE, R0, Lambda ...), defaulting to ``batch_constants()`` = the literal block
-:12-50.  Geometry per pulse and target is NumPy fp64 on the host as the reference computes it; the sample loop
-and the whole back-projection run in HIP kernels.
+:12-50.  Geometry per pulse and target (fp64), the sample loop and the whole back-projection run in HIP kernels.
 """
 from __future__ import annotations
 
@@ -15,10 +14,8 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import check
+from .echo import synth_device
 from .engine import DeviceBuffer, default_context
-
-_PULSE_CHUNK = 4096
-
 
 def batch_constants():
     """sar_batch_sim.py:12-50."""
@@ -111,54 +108,15 @@ def run_physics_spotlight(base_targets, t_vec, pos_sat, vel_sat, heading_deg, sp
     t_vec = np.asarray(t_vec, dtype=np.float64)
     pos_sat = np.asarray(pos_sat, dtype=np.float64)
     vel_sat = np.asarray(vel_sat, dtype=np.float64)
-    n_pulses, n_tgt = t_vec.size, p0.shape[0]
-    d_tf = ctx.to_device(np.ascontiguousarray(t_fast_abs))
-    if out is not None:
-        if out.nbytes < n_pulses * num_samples * 8:
-            raise ValueError("out buffer too small")
-        d_raw, device = out, True
-    else:
-        d_raw = ctx.alloc(n_pulses * num_samples * 8)
-    step = max(1, min(_PULSE_CHUNK, (64 << 20) // max(24 * n_tgt, 1)))
-    for i0 in range(0, n_pulses, step):
-        i1 = min(i0 + step, n_pulses)
-        ps = pos_sat[i0:i1, None, :]
-        p_tgt = p0[None, :, :] + v_tgt[None, None, :] * t_vec[i0:i1, None, None]                   # :127
-        diff_tx = p_tgt - ps
-        dist_tx = _norm3(diff_tx)
-        tau_approx = 2 * dist_tx / Cc
-        p_rx = ps + vel_sat[i0:i1, None, :] * tau_approx[:, :, None]                               # :131
-        dist_rx = _norm3(p_tgt - p_rx)
-        tau = (dist_tx + dist_rx) / Cc
-        b_vec = -ps                                                                                # p_center = 0
-        look = b_vec / _norm3(b_vec)[:, :, None]
-        cos_off = (look[..., 0] * diff_tx[..., 0] + look[..., 1] * diff_tx[..., 1] + look[..., 2] * diff_tx[..., 2]) / dist_tx
-        angle_off = np.arccos(np.clip(cos_off, -1, 1))                                             # :136-139
-        x_val = np.pi * l_ant * np.sin(angle_off) / Lambda
-        gain = np.ones_like(x_val)
-        m = np.abs(x_val) > 1e-6
-        gain[m] = (np.sin(x_val[m]) / x_val[m]) ** 2                                               # :141-144
-        tp = np.empty((i1 - i0, n_tgt, 2), dtype=np.float64)
-        tp[..., 0] = tau
-        tp[..., 1] = -FC * tau                                                                     # :148, revolutions
-        d_tp = ctx.to_device(tp)
-        d_amp = ctx.to_device(np.ascontiguousarray(rcs[None, :] * gain, dtype=np.float32))         # :150
-        check(ctx.lib.sarx_echo_spotlight_dev(ctx.h, d_tp.ptr, d_amp.ptr, d_tf.ptr, i1 - i0, n_tgt, num_samples,
-                                              float(K_RATE), float(T_P), d_raw.ptr + i0 * num_samples * 8), ctx.h)
-        ctx.sync()
-        d_tp.release()
-        d_amp.release()
-    d_tf.release()
-    if device:
+    # per pulse and target: moved target (:127), bistatic delay with the receiver displaced by v_sat * 2 d_tx / C
+    # (:128-133), antenna pattern (:134-144), amplitude rcs * gain (:150): geometry kernel, then the sample kernel
+    d_raw = synth_device(ctx, 2, p0, v_tgt, t_vec, pos_sat, vel_sat, rcs, t_fast_abs, K_RATE, T_P, Cc, FC, l_ant=l_ant,
+                         wavelength=Lambda, out=out)
+    if device or out is not None:
         return d_raw, t_start, num_samples, v_tgt
-    raw = d_raw.download(np.complex64, (n_pulses, num_samples))
+    raw = d_raw.download(np.complex64, (t_vec.size, num_samples))
     d_raw.release()
     return raw, t_start, num_samples, v_tgt
-
-
-def _norm3(v):
-    """Euclidean norm over a last axis of length 3 (np.linalg.norm reduces short axes slowly)."""
-    return np.sqrt(v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1] + v[..., 2] * v[..., 2])
 
 
 class TdbpPlan:
