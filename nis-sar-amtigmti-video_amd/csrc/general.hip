@@ -56,30 +56,6 @@ static hipError_t scale_copy(const cf* in, int in_rows, int in_cols, size_t in_l
     return hipGetLastError();
 }
 
-// Phi_1 / Phi_2 / Phi_3 as a separate element-wise launch, direct fp64 evaluation, any size.
-struct PhaseArgs {
-    cf* buf;
-    const double2* c;      // per azimuth bin
-    int n_az, n_rg;
-    double dt, t_start, t0, df;
-};
-template <int WHICH> __global__ __launch_bounds__(256) void phase_mul_kernel(PhaseArgs a) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= a.n_rg) return;
-    const double tau = __dadd_rn(a.t_start, __dmul_rn((double)j, a.dt));
-    const int ks = (j < (a.n_rg + 1) / 2) ? j : j - a.n_rg;            // numpy.fft.fftfreq order, any parity
-    const double f = (double)ks * a.df;
-    for (int i = blockIdx.y; i < a.n_az; i += gridDim.y) {
-        const double2 c = a.c[i];
-        double p;
-        if (WHICH == 1) { const double d = tau - c.y; p = c.x * d * d; }                          // :272
-        else if (WHICH == 2) p = f * fma(c.x, f, c.y);                                            // :318-324
-        else { const double d = tau - a.t0; p = fma(c.x, tau, c.y * d * d); }                     // :359,375-380
-        cf* x = a.buf + (size_t)i * a.n_rg + j;
-        *x = cmul(*x, cis_rev(p));
-    }
-}
-
 // ---- host-side tables ----------------------------------------------------------------------------
 typedef std::complex<double> zd;
 static void host_fft(std::vector<zd>& a) {           // iterative radix-2, forward, in place
@@ -236,18 +212,6 @@ hipError_t scale_copy_cols(const float2* in, int in_rows, int in_cols, size_t in
 // ---- any-length transforms of the dense [n_az x n_rg] image `d` (in place) ----------------------------------
 #define GCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
-static hipError_t fft_rows(GeneralCsa* g, cf* d, bool inv, hipStream_t st) {
-    const Axis& ax = g->rg;
-    const int B = g->n_az, n = g->n_rg, m = ax.m;
-    if (ax.direct) return rows_pow2(g, d, B, n, inv, st);
-    cf* w = g->work_a;
-    GCK(scale_copy(d, B, n, n, w, B, m, m, nullptr, inv ? ax.chirp_i : ax.chirp_f, 1.0f, st));
-    GCK(rows_pow2(g, w, B, m, false, st));
-    GCK(scale_copy(w, B, m, m, w, B, m, m, nullptr, inv ? ax.bhat_i : ax.bhat_f, 1.0f, st));
-    GCK(rows_pow2(g, w, B, m, true, st));
-    return scale_copy(w, B, n, m, d, B, n, n, nullptr, inv ? ax.chirp_i : ax.chirp_f, inv ? 1.0f / (float)n : 1.0f, st);
-}
-
 // in_shift / out_shift: circular row shifts applied while copying in / out (element r of the transformed sequence is
 // source row (r + in_shift) mod n; destination row r' receives sequence element (r' + out_shift) mod n);
 // pre: optional per-source-row factor (azimuth window)
@@ -268,18 +232,6 @@ static hipError_t fft_cols(GeneralCsa* g, const cf* src, cf* dst, bool inv, hipS
     GCK(cols_pow2(g, wa, wa, wb, m, ld, true, st));
     // the chirp belongs to the sequence index, i.e. to the source row of this copy
     return scale_copy(wb, n, C, ld, dst, n, C, C, nullptr, nullptr, inv ? 1.0f / (float)n : 1.0f, st, out_shift, chirp);
-}
-
-template <int WHICH> static hipError_t phase(GeneralCsa* g, cf* d, hipStream_t st) {
-    PhaseArgs a{};
-    a.buf = d; a.c = (WHICH == 1) ? g->c1 : (WHICH == 2) ? g->c2 : g->c3;
-    a.n_az = g->n_az; a.n_rg = g->n_rg;
-    a.dt = 1.0 / g->p.sample_rate_hz; a.t_start = g->p.t_start_fast_s;
-    a.t0 = 2.0 * g->p.range_ref_m / 299792458.0;
-    a.df = 1.0 / ((double)g->n_rg * a.dt);
-    dim3 grid((g->n_rg + 255) / 256, g->n_az < 16384 ? g->n_az : 16384);
-    hipLaunchKernelGGL(phase_mul_kernel<WHICH>, grid, dim3(256), 0, st, a);
-    return hipGetLastError();
 }
 
 // ---- fused hand-over between two transforms ---------------------------------------------------------
