@@ -227,11 +227,10 @@ static hipError_t fft_cols(GeneralCsa* g, const cf* src, cf* dst, bool inv, hipS
     }
     const cf* chirp = inv ? ax.chirp_i : ax.chirp_f;
     GCK(scale_copy(src, n, C, C, wa, m, ld, ld, chirp, nullptr, 1.0f, st, in_shift, pre));
-    GCK(cols_pow2(g, wa, wa, wb, m, ld, false, st));                       // step A in place on wa, result in wb
-    GCK(scale_copy(wb, m, ld, ld, wa, m, ld, ld, inv ? ax.bhat_i : ax.bhat_f, nullptr, 1.0f, st));
-    GCK(cols_pow2(g, wa, wa, wb, m, ld, true, st));
+    GCK(cols_pow2(g, wa, wa, wb, m, ld, false, st, inv ? ax.bhat_i : ax.bhat_f));   // filter spectrum in the epilogue; result in wb
+    GCK(cols_pow2(g, wb, wb, wa, m, ld, true, st));                                   // result in wa
     // the chirp belongs to the sequence index, i.e. to the source row of this copy
-    return scale_copy(wb, n, C, ld, dst, n, C, C, nullptr, nullptr, inv ? 1.0f / (float)n : 1.0f, st, out_shift, chirp);
+    return scale_copy(wa, n, C, ld, dst, n, C, C, nullptr, nullptr, inv ? 1.0f / (float)n : 1.0f, st, out_shift, chirp);
 }
 
 // ---- fused hand-over between two transforms ---------------------------------------------------------

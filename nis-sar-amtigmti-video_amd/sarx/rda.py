@@ -12,6 +12,40 @@ from ._ffi import check
 from .engine import default_context
 
 
+class RdaPlan:
+    """sarx_rda_plan: filter spectrum, window, axes and scratch for one (n_ranges, n_pulses, radar) combination."""
+
+    def __init__(self, ctx, n_r, n_p, prm):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        check(ctx.lib.sarx_rda_plan_create(ctx.h, n_r, n_p, C.byref(prm), C.byref(self.h)), ctx.h)
+        ctx._plans.add(self)          # closed with the context, before sarx_destroy
+
+    def close(self):
+        if self.h and self.ctx.h is not None:
+            self.ctx.lib.sarx_rda_plan_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_plans = {}
+
+
+def _plan(ctx, n_r, n_p, prm):
+    key = (id(ctx), n_r, n_p) + tuple(getattr(prm, f) for f, _ in prm._fields_)
+    plan = _plans.get(key)
+    if plan is None or plan.h is None:
+        while len(_plans) >= 2:                       # plans hold several full-image buffers
+            _plans.pop(next(iter(_plans))).close()
+        plan = _plans[key] = RdaPlan(ctx, n_r, n_p, prm)
+    return plan
+
+
 def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
                   platform_speed_mps, range_grp_m, *, ctx=None, intermediates=True):
     """phist: [num_ranges x num_pulses] complex (the scripts pass ``raw_data.T``).
@@ -31,16 +65,12 @@ def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     x = np.ascontiguousarray(a.T, dtype=np.complex64)
     prm = _ffi.RadarParams(center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
                            platform_speed_mps, range_grp_m, 0.0)
-    h = C.c_void_p()
-    check(lib.sarx_rda_plan_create(ctx.h, n_r, n_p, C.byref(prm), C.byref(h)), ctx.h)
-    try:
-        mag = np.empty((n_p, n_r), dtype=np.float32)
-        stages = [np.empty((n_p, n_r), dtype=np.complex64) if intermediates else None for _ in range(3)]
-        ptr = [s.ctypes.data if s is not None else None for s in stages]
-        check(lib.sarx_rda_focus_host(h, x.ctypes.data, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
-        r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
-        check(lib.sarx_rda_axes(h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
-    finally:
-        lib.sarx_rda_plan_destroy(h)
+    plan = _plan(ctx, n_r, n_p, prm)
+    mag = np.empty((n_p, n_r), dtype=np.float32)
+    stages = [np.empty((n_p, n_r), dtype=np.complex64) if intermediates else None for _ in range(3)]
+    ptr = [s.ctypes.data if s is not None else None for s in stages]
+    check(lib.sarx_rda_focus_host(plan.h, x.ctypes.data, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
+    r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
+    check(lib.sarx_rda_axes(plan.h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
     pc, rd, rc = (s.T if s is not None else None for s in stages)
     return mag, r_ax, c_ax, pc, rd, rc, fd
