@@ -136,7 +136,8 @@ def sar_focus_csa_lean(phist, center_wavelength_m, pulse_width_sec, chirp_rate_h
 
     Used only as the timed ``cpu_baseline`` ("port") and for large-size spot
     checks; equality with :func:`sar_focus_csa` is asserted in tests.
-    ``workers``>1 uses scipy.fft threads (stated in the bench line as cores).
+    ``workers``>1 threads the azimuth FFTs (scipy.fft) and runs the row blocks in a thread pool
+    (stated in the bench line as cores).
     """
     import scipy.fft as sfft
     S = np.array(phist, dtype=np.complex128)       # private copy, worked on in place
@@ -147,18 +148,27 @@ def sar_focus_csa_lean(phist, center_wavelength_m, pulse_width_sec, chirp_rate_h
     D, Cs, tau_ref = migration_factors(fa, lam, Vr, R_ref)
     R_vec = c * tau / 2.0
     S = sfft.fft(S, axis=0, overwrite_x=True, workers=workers)
-    for i0 in range(0, n_az, block):
+
+    def rows(i0):
         sl = slice(i0, min(i0 + block, n_az))
         Csc, Dc, trc = Cs[sl, None], D[sl, None], tau_ref[sl, None]
         blk = S[sl]
         blk *= np.exp(-1j * np.pi * Kr * Csc * (tau[None, :] - trc) ** 2)
-        blk = sfft.fft(blk, axis=1, overwrite_x=True, workers=workers)
+        blk = sfft.fft(blk, axis=1, overwrite_x=True, workers=1 if workers > 1 else workers)
         blk *= np.exp(1j * (np.pi * fr[None, :] ** 2 / (Kr * (1.0 + Csc))
                             + 4.0 * np.pi * R_ref * Csc * fr[None, :] / c))
-        blk = sfft.ifft(blk, axis=1, overwrite_x=True, workers=workers)
+        blk = sfft.ifft(blk, axis=1, overwrite_x=True, workers=1 if workers > 1 else workers)
         blk *= np.exp(1j * (4.0 * np.pi * R_vec[None, :] * Dc / lam
                             - np.pi * Kr * Csc * (1.0 + Csc) * (tau[None, :] - 2.0 * R_ref / c) ** 2))
         S[sl] = blk
+
+    if workers > 1:                                 # row blocks in parallel (NumPy releases the GIL in ufuncs and FFTs)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(rows, range(0, n_az, block)))
+    else:
+        for i0 in range(0, n_az, block):
+            rows(i0)
     S = sfft.ifft(S, axis=0, overwrite_x=True, workers=workers)
     t_slow = np.arange(n_az) / prf_hz
     t_slow = t_slow - np.mean(t_slow)
