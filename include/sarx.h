@@ -192,7 +192,8 @@ int sarx_echo_synth_dev(sarx_ctx* ctx, const double* d_tau_pb, const float* d_am
 
 /* Per pulse and target geometry of the three echo models on the device (fp64): fills the d_tau_pb table (and, for
  * model 2, d_amp_pt) that the sample kernels consume.  All pointers are device pointers.
- *   model 0: run_physics_engine (sar_satellite_sim.py:268-272)          needs d_tgt_pos, d_tx_pos
+ *   model 0: run_physics_engine (sar_satellite_sim.py:268-272)          needs d_tgt_pos, d_tx_pos; optional d_tgt_vel +
+ *            d_t_pulse move the targets: run_moving_physics (sar_satellite_moving_sim.py:137-145)
  *   model 1: run_bistatic_physics_gpu (sar_ati_dcpa_sim_csa.py:151-160)  + d_tgt_vel[3], d_t_pulse, d_aux = receiver positions
  *   model 2: run_physics_spotlight (sar_batch_sim.py:127-150)           + d_aux = platform velocities, d_rcs, l_ant, wavelength */
 int sarx_echo_geometry_dev(sarx_ctx* ctx, int model, int n_pulses, int n_targets, const double* d_tgt_pos,

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(ECHO_THREADS) void echo_synth_kernel(EchoArgs a) {
 // revolutions, and for the spotlight model the amplitude rcs * sinc^2 antenna gain.  The reference does this part in
 // NumPy / torch on [pulses x targets x 3] arrays (36 M pairs and 0.9 GB per clutter call of the two-channel script);
 // here it is one small launch whose table the sample kernel above consumes without a host round trip.
-//   model 0  run_physics_engine        (sar_satellite_sim.py:268-272): tau = 2 d / C, pb = -2 FC d / C
+//   model 0  run_physics_engine        (sar_satellite_sim.py:268-272): tau = 2 d / C, pb = -2 FC d / C; with a target
+//            velocity run_moving_physics (sar_satellite_moving_sim.py:137-145); run_custom_physics (sar_vehicle_sim.py:108-114)
 //   model 1  run_bistatic_physics_gpu  (sar_ati_dcpa_sim_csa.py:151-160): targets move, tau = (d_tx + d_rx) / C, pb = -FC tau
 //   model 2  run_physics_spotlight     (sar_batch_sim.py:127-150): receiver displaced by v_sat * 2 d_tx / C, antenna gain
 // ------------------------------------------------------------------------------
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void echo_geometry_kernel(EchoGeoArgs a) {
     if (b >= a.n_targets) return;
     const double t = a.t_pulse ? a.t_pulse[i] : 0.0;
     double px = a.tgt_pos[3 * b], py = a.tgt_pos[3 * b + 1], pz = a.tgt_pos[3 * b + 2];
-    if (a.model != 0) { px += a.tgt_vel[0] * t; py += a.tgt_vel[1] * t; pz += a.tgt_vel[2] * t; }
+    if (a.tgt_vel) { px += a.tgt_vel[0] * t; py += a.tgt_vel[1] * t; pz += a.tgt_vel[2] * t; }   // model 0: optional (run_moving_physics)
     const double sx = a.tx_pos[3 * i], sy = a.tx_pos[3 * i + 1], sz = a.tx_pos[3 * i + 2];
     const double dx = px - sx, dy = py - sy, dz = pz - sz;
     const double d_tx = sqrt(dx * dx + dy * dy + dz * dz);

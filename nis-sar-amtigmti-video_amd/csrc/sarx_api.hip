@@ -605,6 +605,7 @@ int sarx_echo_geometry_dev(sarx_ctx* c, int model, int n_pulses, int n_targets, 
     if (n_pulses <= 0 || n_targets <= 0 || n_pulses > 65535) return fail(c, SARX_ERR_INVALID, "echo sizes must be positive (n_pulses <= 65535 per call)");
     if (!tgt_pos || !tx_pos || !tau_pb) return fail(c, SARX_ERR_INVALID, "NULL pointer");
     if (model != 0 && (!tgt_vel || !t_pulse || !aux)) return fail(c, SARX_ERR_INVALID, "models 1 and 2 need target velocity, pulse times and aux");
+    if (model == 0 && tgt_vel && !t_pulse) return fail(c, SARX_ERR_INVALID, "moving targets need the pulse times");
     if (model == 2 && (!rcs || !amp_pt || !(wavelength > 0))) return fail(c, SARX_ERR_INVALID, "model 2 needs rcs, amp_pt and the wavelength");
     if (!(c_light > 0) || !(fc > 0)) return fail(c, SARX_ERR_INVALID, "C and FC must be positive");
     EchoGeoArgs a{};

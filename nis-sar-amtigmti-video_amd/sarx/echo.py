@@ -88,6 +88,43 @@ def run_physics_engine(targets, pos_sat, t_vec, *, BW=None, T_p=None, R0=None, C
     return _download(d_raw, (pos_sat.shape[0], num_samples)), t_start_fast, fs
 
 
+def run_moving_physics(targets, t_vec, pos_sat, vel_target, *, BW=None, T_p=None, R0=None, C=None, FC=None, ctx=None):
+    """Monostatic echo of targets moving at ``vel_target``; drop-in for sar_satellite_moving_sim.py:111-159.
+    returns (raw [len(t_vec) x 13200] complex64, t_start_fast, fs)"""
+    k = radar.reference_constants()
+    BW, T_p, R0 = (BW or k["BW"]), (T_p or k["T_p"]), (R0 or k["R0"])
+    C, FC = (C or k["C"]), (FC or k["FC"])
+    ctx = ctx or default_context()
+    fs = 600e6                                                      # :114
+    num_samples = int(22e-6 * fs)
+    t_start_fast = (2 * R0 / C) - (T_p / 2) - 1e-6                  # :116
+    t_fast_abs = t_start_fast + np.linspace(0, num_samples / fs, num_samples)   # :117-118
+    t_vec = np.asarray(t_vec, dtype=np.float64)
+    t_pos = np.array([t["position"] for t in targets], dtype=np.float64)
+    amp = np.sqrt(np.array([t["rcs"] for t in targets], dtype=np.float64))
+    pos_sat = np.asarray(pos_sat, dtype=np.float64)[: t_vec.size]
+    # P(t) = P0 + V t (:137), tau = 2 d / C, phase -4 pi FC d / C (:143-144): geometry kernel
+    d_raw = synth_device(ctx, 0, t_pos, np.asarray(vel_target, dtype=np.float64), t_vec, pos_sat, None, amp, t_fast_abs, BW / T_p,
+                         T_p, C, FC)
+    return _download(d_raw, (t_vec.size, num_samples)), t_start_fast, fs
+
+
+def run_custom_physics(targets, t_vec, pos, tuned_prp, t_p, fc, bw, *, R0=None, C=None, ctx=None):
+    """The vehicle script's monostatic echo (2048 samples at 360 MHz); drop-in for sar_vehicle_sim.py:83-128
+    (``tuned_prp`` is accepted and unused, as in the reference; R0 and C are its module globals).  returns raw complex64"""
+    k = radar.reference_constants()
+    R0, C = (R0 or k["R0"]), (C or k["C"])
+    ctx = ctx or default_context()
+    fs, num_samples = 360e6, 2048                                   # :85-86
+    t_start_fast = (2 * R0 / C) - (num_samples / fs) / 2            # :89
+    t_fast_abs = t_start_fast + np.linspace(0, num_samples / fs, num_samples)   # :88,100
+    t_pos = np.array([t["position"] for t in targets], dtype=np.float64)
+    amp = np.sqrt(np.array([t["rcs"] for t in targets], dtype=np.float64))
+    pos = np.asarray(pos, dtype=np.float64)[: len(t_vec)]
+    d_raw = synth_device(ctx, 0, t_pos, None, None, pos, None, amp, t_fast_abs, bw / t_p, t_p, C, fc)
+    return _download(d_raw, (pos.shape[0], num_samples))
+
+
 def run_bistatic_physics_gpu(targets, t_vec, pos_tx_np, vel_tx_np, rx_offset_dist, vel_target_np, *, FS=None,
                              BW=None, T_p=None, R0=None, C=None, FC=None, window_sec=22e-6, ctx=None):
     """Bistatic (one Tx, offset Rx) echo of moving point targets; drop-in for

@@ -231,8 +231,10 @@ def orbit_track(t_vec, consts=None):
     return pos, vel
 
 
-def echo_monostatic(targets, pos_sat, n_rg, fs, t_start_fast, fc, kr, t_p, linspace_grid=True):
-    """run_physics_engine's signal model (sar_satellite_sim.py:254-302).
+def echo_monostatic(targets, pos_sat, n_rg, fs, t_start_fast, fc, kr, t_p, linspace_grid=True, t_vec=None, vel_target=None):
+    """run_physics_engine's signal model (sar_satellite_sim.py:254-302); with ``t_vec`` and ``vel_target`` the targets
+    move as p0 + v t: run_moving_physics (sar_satellite_moving_sim.py:111-159); run_custom_physics
+    (sar_vehicle_sim.py:83-128) is the same model on a 2048-sample grid.
 
     tau=2d/C, phase_base=-4*pi*FC*d/C, chirp pi*k*(t-tau-Tp/2)^2 gated to
     |t-tau-Tp/2|<=Tp/2.  ``linspace_grid`` reproduces the reference's
@@ -245,7 +247,8 @@ def echo_monostatic(targets, pos_sat, n_rg, fs, t_start_fast, fc, kr, t_p, linsp
     amp = np.sqrt(np.array([t["rcs"] for t in targets], dtype=np.float64))
     raw = np.zeros((len(pos_sat), n_rg), dtype=np.complex128)
     for i in range(len(pos_sat)):
-        dist = np.sqrt(np.sum((p - pos_sat[i]) ** 2, axis=1))
+        pi_ = p if vel_target is None else p + np.asarray(vel_target, dtype=np.float64) * t_vec[i]
+        dist = np.sqrt(np.sum((pi_ - pos_sat[i]) ** 2, axis=1))
         tau = 2 * dist / C
         phase_base = -4.0 * np.pi * fc * dist / C
         t_local = t_abs[None, :] - tau[:, None]

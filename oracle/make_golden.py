@@ -19,6 +19,8 @@ values; reference outputs are complex128):
   destroyer.npz            generate_destroyer        (vehicle_targets.py:102-141)
   echo_mono.npz            run_physics_engine        (sar_satellite_sim.py:211-305)
   echo_bistatic.npz        run_bistatic_physics_gpu  (sar_ati_dcpa_sim_csa.py:106-181)
+  echo_moving.npz          run_moving_physics        (sar_satellite_moving_sim.py:111-159)
+  echo_vehicle.npz         run_custom_physics        (sar_vehicle_sim.py:83-128)
   spot_<a|b>.npz           run_physics_spotlight     (sar_batch_sim.py:85-169) + calculate_raw_snr_db (:54-64)
   tdbp_<a|b>.npz           tdbp_gpu                  (sar_batch_sim.py:171-238), moving-target and static focus
 """
@@ -163,7 +165,33 @@ def main():
         print("echo_bistatic:", raw_b.shape, np.abs(raw_b).max())
     except ImportError:
         print("torch missing: echo_bistatic.npz not regenerated")
+    make_mono_variants()
     make_tdbp()
+
+
+def make_mono_variants():
+    """echo_moving.npz / echo_vehicle.npz: run_moving_physics (sar_satellite_moving_sim.py:111-159) and
+    run_custom_physics (sar_vehicle_sim.py:83-128); both hard-code their sample grids."""
+    kk = orc.reference_radar_constants()
+    tgts = [{"position": np.array([30.0, -40.0, 0.0]), "rcs": 10.0},
+            {"position": np.array([-80.0, 25.0, 5.0]), "rcs": 250.0},
+            {"position": np.array([5.0, 60.0, 12.0]), "rcs": 40.0}]
+    t_vec = np.linspace(-0.2, 0.2, 4)
+    pos_tx, _ = orc.orbit_track(t_vec, kk)
+    env = {"np": np, "BW": 5e6, "T_p": kk["T_p"], "R0": kk["R0"], "C": kk["C"], "FC": kk["FC"]}
+    mov = extract("sar_satellite_moving_sim.py", "run_moving_physics", env)
+    vel = [12.0, -7.0, 0.0]
+    raw, t0, fs = quiet(mov, tgts, t_vec, pos_tx, vel)
+    np.savez_compressed(os.path.join(OUT, "echo_moving.npz"), raw=raw, t_start_fast=t0, fs=fs, t_vec=t_vec, pos_sat=pos_tx,
+                        vel_target=np.array(vel), tgt_pos=np.array([t["position"] for t in tgts]),
+                        tgt_rcs=np.array([t["rcs"] for t in tgts]), BW=5e6, T_p=kk["T_p"], FC=kk["FC"], R0=kk["R0"])
+    env = {"np": np, "R0": 9000.0, "C": kk["C"]}
+    cus = extract("sar_vehicle_sim.py", "run_custom_physics", env)
+    pos = np.stack([np.linspace(-40, 40, 6), np.full(6, -6000.0), np.full(6, 6708.2)], axis=1)
+    raw = quiet(cus, tgts, np.arange(6) / 1000.0, pos, 1e-3, 4e-6, 10e9, 150e6)
+    np.savez_compressed(os.path.join(OUT, "echo_vehicle.npz"), raw=raw, pos=pos, t_p=4e-6, fc=10e9, bw=150e6, R0=9000.0,
+                        tgt_pos=np.array([t["position"] for t in tgts]), tgt_rcs=np.array([t["rcs"] for t in tgts]))
+    print("echo_moving:", np.abs(np.load(os.path.join(OUT, "echo_moving.npz"))["raw"]).max(), "echo_vehicle:", np.abs(raw).max())
 
 
 def make_tdbp():

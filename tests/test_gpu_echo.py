@@ -35,6 +35,22 @@ def test_bistatic_matches_reference_fixture():
     assert orc.rel_l2(raw, g["raw"]) < 2e-6
 
 
+def test_moving_and_vehicle_variants_match_reference_fixtures():
+    """run_moving_physics (sar_satellite_moving_sim.py:111-159) and run_custom_physics (sar_vehicle_sim.py:83-128)."""
+    import sarx
+    g = load_golden("echo_moving.npz")
+    raw, t0, fs = sarx.run_moving_physics(_targets(g), g["t_vec"], g["pos_sat"], g["vel_target"], BW=float(g["BW"]),
+                                          T_p=float(g["T_p"]), FC=float(g["FC"]), R0=float(g["R0"]))
+    assert raw.shape == g["raw"].shape and t0 == float(g["t_start_fast"]) and fs == float(g["fs"])
+    assert orc.rel_l2(raw, g["raw"]) < 2e-6
+    np.testing.assert_array_equal(raw == 0, g["raw"] == 0)
+    g = load_golden("echo_vehicle.npz")
+    raw = sarx.run_custom_physics(_targets(g), np.arange(len(g["pos"])) / 1000.0, g["pos"], 1e-3, float(g["t_p"]), float(g["fc"]),
+                                  float(g["bw"]), R0=float(g["R0"]))
+    assert raw.shape == g["raw"].shape and raw.dtype == np.complex64
+    assert orc.rel_l2(raw, g["raw"]) < 2e-6
+
+
 def test_many_targets_and_focus_chain():
     """600 scatterers (more than one LDS chunk) x 256 pulses; then GPU echo -> GPU focus equals
     oracle echo -> oracle focus."""

@@ -79,6 +79,20 @@ def test_echo_models_match_reference():
     assert orc.rel_l2(raw, g["raw"]) < 1e-6
 
 
+def test_moving_and_vehicle_echo_oracle_matches_reference():
+    """run_moving_physics (sar_satellite_moving_sim.py:111-159), run_custom_physics (sar_vehicle_sim.py:83-128)."""
+    g = load_golden("echo_moving.npz")
+    tg = [{"position": p, "rcs": r} for p, r in zip(g["tgt_pos"], g["tgt_rcs"])]
+    o = orc.echo_monostatic(tg, g["pos_sat"], g["raw"].shape[1], float(g["fs"]), float(g["t_start_fast"]), float(g["FC"]),
+                            float(g["BW"]) / float(g["T_p"]), float(g["T_p"]), t_vec=g["t_vec"], vel_target=g["vel_target"])
+    assert orc.rel_l2(o, g["raw"]) < 1e-12
+    g = load_golden("echo_vehicle.npz")
+    n, fs = 2048, 360e6
+    o = orc.echo_monostatic(tg, g["pos"], n, fs, (2 * float(g["R0"]) / orc.C_LIGHT) - (n / fs) / 2, float(g["fc"]),
+                            float(g["bw"]) / float(g["t_p"]), float(g["t_p"]))
+    assert orc.rel_l2(o, g["raw"]) < 1e-12
+
+
 def test_reference_constants():
     k = orc.reference_radar_constants()
     assert abs(k["V_sat"] - 7701.0) < 5 and abs(k["R0"] - 509.4e3) < 200
