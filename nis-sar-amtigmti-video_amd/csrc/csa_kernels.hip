@@ -292,6 +292,7 @@ hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int 
         case 32: return launch_az_r<32>(w, inv, epi, a, nq, st);
         case 64: return launch_az_r<64>(w, inv, epi, a, nq, st);
         case 128: return launch_az_r<128>(w, inv, epi, a, nq, st);
+        case 256: return w == 32 ? launch_az_rw<256, 32>(inv, epi, a, nq, st) : hipErrorInvalidValue;   // 32768-row columns (general.hip)
     }
     return hipErrorInvalidValue;
 }

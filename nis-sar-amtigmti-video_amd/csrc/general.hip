@@ -93,9 +93,11 @@ static hipError_t upload(const std::vector<zd>& h, cf** d) {
     if (e != hipSuccess) return e;
     return hipMemcpy(*d, f.data(), f.size() * sizeof(cf), hipMemcpyHostToDevice);
 }
-static hipError_t axis_init(Axis& ax, int n, int m_max) {
+// direct_max: largest power of two transformed without chirp-z; split_order: a 32768-point spectrum is stored in the
+// order of the split line FFT (range axis), the column transforms (azimuth axis) keep natural order
+static hipError_t axis_init(Axis& ax, int n, int m_max, int direct_max, bool split_order) {
     ax.n = n;
-    if (is_pow2(n) && n >= 16 && n <= 16384) { ax.direct = true; ax.m = n; return hipSuccess; }
+    if (is_pow2(n) && n >= 16 && n <= direct_max) { ax.direct = true; ax.m = n; return hipSuccess; }
     int m = 16;
     while (m < 2 * n - 1) m <<= 1;
     if (m > m_max) return hipErrorInvalidValue;
@@ -112,7 +114,7 @@ static hipError_t axis_init(Axis& ax, int n, int m_max) {
     }
     host_fft(b);
     host_fft(bi);
-    if (m == 32768) {                  // spectrum order of the split line FFT: position k1*256 + k2 holds bin k1 + 128*k2
+    if (m == 32768 && split_order) {   // spectrum order of the split line FFT: position k1*256 + k2 holds bin k1 + 128*k2
         std::vector<zd> p(m), pi(m);
         for (int k1 = 0; k1 < SPLIT_A; ++k1)
             for (int k2 = 0; k2 < SPLIT_B; ++k2) {
@@ -175,7 +177,7 @@ static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n
     AzArgs a{};
     a.scale = 1.0f / (float)n;
     a.n_rg = ld;
-    a.tw_n = g->tw_all + n;
+    a.tw_n = n <= 16384 ? g->tw_all + n : nullptr;      // table twiddles exist up to 16384; the kernels use v_sin/v_cos
     const int epi_last = inv ? AZ_EPI_SCALE : (rowvec ? AZ_EPI_ROWVEC : AZ_EPI_NONE);
     a.rowvec = rowvec;
     if (S == n) {
@@ -549,7 +551,7 @@ void general_csa_destroy(GeneralCsa* g) {
 }
 
 GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm, const float2* tw_all, std::string& err) {
-    if (n_az < 2 || n_rg < 2 || n_rg > 16384 || n_az > 16384) { err = "sizes must be in [2, 16384]"; return nullptr; }
+    if (n_az < 2 || n_rg < 2 || n_rg > 16384 || n_az > 32768) { err = "n_rg must be in [2, 16384], n_az in [2, 32768]"; return nullptr; }
     GeneralCsa* g = new GeneralCsa();
     g->n_az = n_az; g->n_rg = n_rg; g->p = *prm; g->tw_all = tw_all;
     g->ldc = (n_rg + 31) / 32 * 32;
@@ -559,11 +561,11 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
         return (GeneralCsa*)nullptr;
     };
     hipError_t e;
-    if ((e = axis_init(g->az, n_az, 16384)) != hipSuccess) {
-        if (e == hipErrorInvalidValue) { err = "a non-power-of-two n_az must be <= 8192 (chirp-z length 16384)"; general_csa_destroy(g); return nullptr; }
+    if ((e = axis_init(g->az, n_az, 32768, 32768, false)) != hipSuccess) {
+        if (e == hipErrorInvalidValue) { err = "a non-power-of-two n_az must be <= 16384 (chirp-z length 32768)"; general_csa_destroy(g); return nullptr; }
         return bail("azimuth tables", e);
     }
-    if ((e = axis_init(g->rg, n_rg, 32768)) != hipSuccess) return bail("range tables", e);
+    if ((e = axis_init(g->rg, n_rg, 32768, 16384, true)) != hipSuccess) return bail("range tables", e);
     // migration factors in natural fftfreq order, any parity (sar_ati_dcpa_sim_csa.py:225,244-249,262)
     const double C0 = 299792458.0, lam = prm->wavelength_m, Kr = prm->chirp_rate_hz_s, Vr = prm->platform_speed_mps,
                  Rref = prm->range_ref_m, fa_step = 1.0 / ((double)n_az * (1.0 / prm->prf_hz));

@@ -27,6 +27,8 @@ def test_reference_fixture_96x80():
 @pytest.mark.parametrize("n_az,n_rg", [(255, 257), (300, 200), (5, 7), (64, 100), (100, 64), (33, 1024),
                                        (48, 13200),      # native range extent: chirp-z over a 32768-point line
                                        (7199, 48),       # native azimuth extent: chirp-z over 16384 rows
+                                       (9001, 40),       # chirp-z over 32768 rows (128 x 256 column transform)
+                                       (32768, 32),      # the largest azimuth extent, direct
                                        (1000, 3000)])
 def test_any_size_vs_oracle(n_az, n_rg):
     import sarx

@@ -217,7 +217,7 @@ def test_corner_turn_multilook_noise(sx, ctx):
 def test_errors_are_loud(sx, ctx):
     k = orc.scaled_radar(64, 64)
     with pytest.raises(sx.SarxError):
-        sx.CsaPlan(ctx, 9000, 64, *orc.focus_args(k))              # non power of two n_az > 8192
+        sx.CsaPlan(ctx, 20000, 64, *orc.focus_args(k))             # non power of two n_az > 16384
     with pytest.raises(sx.SarxError):
         sx.CsaPlan(ctx, 1, 64, *orc.focus_args(k))
     with pytest.raises(sx.SarxError):
