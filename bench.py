@@ -71,9 +71,9 @@ def main():
 
     import sarx
     from sarx import _ffi, radar
-    from sarx.batch import RcclStackComm
 
-    ctx = sarx.Context(local_rank)
+    n_dev = max(1, sarx.device_count())
+    ctx = sarx.Context(local_rank % n_dev)              # one rank per GPU; wraps only when ranks outnumber GPUs (tests)
     n = a.size
     K, W = a.steps, a.warmup
     flags = 0 if a.unfused else _ffi.FUSE_RANGE
@@ -81,7 +81,8 @@ def main():
     d_in, d_img = ctx.alloc(n * n * 8), ctx.alloc(n * n * 8)
     ctx.fill_noise(d_in, n * n, 1000 + rank)
 
-    comm = d_slot = d_recv = None
+    comm = host_comm = d_slot = d_recv = None
+    collective = None
     slot_bytes = (n // LOOKS) * (n // LOOKS) * 4
     force_comm = os.environ.get("SARX_BENCH_FORCE_COMM") == "1"     # exercise the gather path on one GPU
     if world > 1 or force_comm:
@@ -91,9 +92,44 @@ def main():
             box = [uid]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        comm = RcclStackComm(ctx, world, rank, bootstrap)
-        d_slot = ctx.alloc(slot_bytes * 2)                # double-buffered send slots
-        d_recv = ctx.alloc(slot_bytes * world * 2)        # double-buffered round blocks
+        # RCCL over xGMI is the collective.  If its bootstrap fails on every rank alike (it needs dmabuf IPC,
+        # HSA_ENABLE_IPC_MODE_LEGACY=0), the stack slots travel through the gloo group instead - slower, said so in
+        # the JSON line - rather than losing the whole scaling run.
+        uid, ok = None, 1
+        if rank == 0:
+            try:
+                uid = ctx.comm_unique_id()
+            except Exception as exc:                          # noqa: BLE001
+                print(f"[bench rank 0] RCCL unique id failed: {exc}", file=sys.stderr, flush=True)
+        uid = bootstrap(uid)                                  # every rank takes part, also after a failure on rank 0
+        if uid is None:
+            ok = 0
+        else:
+            try:
+                ctx.comm_init(uid, world, rank)
+                comm = True
+            except Exception as exc:                          # noqa: BLE001
+                ok = 0
+                print(f"[bench rank {rank}] RCCL init failed: {exc}", file=sys.stderr, flush=True)
+        if dist is not None:
+            import torch
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            collective = "RCCL all-gather of the stack slot"
+            d_slot = ctx.alloc(slot_bytes * 2)                # double-buffered send slots
+            d_recv = ctx.alloc(slot_bytes * world * 2)        # double-buffered round blocks
+        else:
+            if comm is not None:
+                ctx.lib.sarx_comm_destroy(ctx.h)
+            comm = None
+            from sarx.batch import TorchStackComm
+            host_comm = TorchStackComm() if dist is not None else None
+            collective = "gloo all-gather of the stack slot through host memory (RCCL init failed)"
+            d_slot = ctx.alloc(slot_bytes * 2)
+
+    import numpy as np
 
     def step(s, mark):
         if mark and 2 * s + 1 < 256:
@@ -106,6 +142,9 @@ def main():
             ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, d_slot.ptr + (s & 1) * slot_bytes, n, n, LOOKS)
             ctx.lib.sarx_allgather_dev(ctx.h, d_slot.ptr + (s & 1) * slot_bytes,
                                        d_recv.ptr + (s & 1) * slot_bytes * world, slot_bytes)
+        elif host_comm is not None:
+            ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, d_slot.ptr, n, n, LOOKS)
+            host_comm.all_gather(d_slot.download(np.float32, (n // LOOKS, n // LOOKS)))
 
     def barrier():
         ctx.sync()
@@ -178,7 +217,7 @@ def main():
                        "frames_per_step_per_gpu": 1, "range_passes": "fused 2+3" if not a.unfused else "separate",
                        "image_layout": "[n_az x n_rg]; img.T returned as a view like the reference",
                        "parallelism": f"frames sharded 1/GPU x{world}" +
-                                      ("; 16x16 multilook + RCCL all-gather of the stack slot per step" if world > 1 else "")},
+                                      (f"; 16x16 multilook + {collective} per step" if collective else "")},
             "roofline": {"bound": "hbm", "kernel": ("range_fused_wl_kernel<false> (FFT.Phi2.IFFT.Phi3, one HBM round trip)"
                                                     if (not a.unfused and n == 16384) else
                                                     "range_pass_kernel<fused>" if not a.unfused else

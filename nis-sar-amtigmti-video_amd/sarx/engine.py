@@ -219,6 +219,13 @@ class CsaPlan:
 _default_ctx = {}
 
 
+def device_count():
+    """Number of HIP devices visible to this process (does not create a context)."""
+    n = C.c_int()
+    check(_ffi.load().sarx_device_count(C.byref(n)), None)
+    return n.value
+
+
 def default_context(device_id=0):
     """Process-wide Context per device (created on first use)."""
     c = _default_ctx.get(device_id)

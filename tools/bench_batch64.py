@@ -39,7 +39,8 @@ def main():
     from sarx import _ffi, radar
     from sarx.batch import RcclStackComm, rounds, shard_frames
 
-    ctx = sarx.Context(local_rank)
+    n_dev = max(1, sarx.device_count())
+    ctx = sarx.Context(local_rank % n_dev)              # one rank per GPU; wraps only when ranks outnumber GPUs (tests)
     n, px = a.size, a.size * a.size
     plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE)
     raw1, raw2, s1, s2 = (ctx.alloc(px * 8) for _ in range(4))
