@@ -52,18 +52,20 @@ def main():
     still = np.array([0.0, 0.0, 0.0])
     t0 = time.time()
     raw = []
-    for off in (-d_rx / 2, d_rx / 2):                                 # :190-197
-        r, t_start_fast = sarx.run_bistatic_physics_gpu(destroyer_targets, t_vec, pos_tx, vel_tx, off, velocity_ship)
+    for off in (-d_rx / 2, d_rx / 2):                                 # :190-197; the pulses stay on the GPU
+        r, t_start_fast = sarx.run_bistatic_physics_gpu(destroyer_targets, t_vec, pos_tx, vel_tx, off, velocity_ship, device=True)
         if clutter_targets:
-            r = r + sarx.run_bistatic_physics_gpu(clutter_targets, t_vec, pos_tx, vel_tx, off, still)[0]
+            sarx.run_bistatic_physics_gpu(clutter_targets, t_vec, pos_tx, vel_tx, off, still, add_to=r)      # raw += clutter
         raw.append(r)
     t_echo = time.time() - t0
 
     t0 = time.time()
     res = sarx.focus_ati_dpca(raw[0], raw[1], k["Lambda"], T_p, BW / T_p, FS, PRF, V_eff, k["R0"], t_start_fast)   # :402-419
     t_proc = time.time() - t0
+    for r in raw:
+        r.release()
     print(f"echo synthesis {t_echo:.2f} s, pulse shift + 2x CSA focus + ATI/DPCA {t_proc:.2f} s "
-          f"({raw[0].shape[0] - 1} x {raw[0].shape[1]} per channel, host<->device copies included)")
+          f"({raw[0].shape[0] - 1} x {raw[0].shape[1]} per channel; echoes never leave the GPU, products downloaded)")
     print(f"peak |slc1| = {res['max_mag']:.4g}; balance phase {np.degrees(np.angle(res['sum_interf'])):.3f} deg; "
           f"masked pixels {int((res['slc1_mag'] > 0.05 * res['max_mag']).sum())}")
     np.savez(a.out, slc1=res["slc1"], slc2=res["slc2"], range_axis=res["range_axis"], cross_range=res["cross_range"])   # :457-461

@@ -185,10 +185,11 @@ int sarx_power_stats_dev(sarx_ctx* ctx, const void* d_buf, size_t n, double* max
  *      (sar_ati_dcpa_sim_csa.py:137-178) ---------------------------------------
  * raw[i][j] = sum_b amp[b] * [|u|<=Tp/2] * exp(2*pi*i*(pb[i][b] + 0.5*kr*u^2)),  u = t_fast[j]-tau[i][b]-Tp/2
  * d_tau_pb: [n_pulses][n_targets] pairs of doubles {tau seconds, carrier phase in revolutions};
- * d_amp: [n_targets] float sqrt(rcs); d_t_fast: [n_samples] double; d_raw: [n_pulses][n_samples] complex64 */
+ * d_amp: [n_targets] float sqrt(rcs); d_t_fast: [n_samples] double; d_raw: [n_pulses][n_samples] complex64;
+ * accumulate != 0 adds to d_raw (a second target set, e.g. the clutter field of sar_ati_dcpa_sim_csa.py:193-196) */
 int sarx_echo_synth_dev(sarx_ctx* ctx, const double* d_tau_pb, const float* d_amp, const double* d_t_fast,
                         int n_pulses, int n_targets, int n_samples, double chirp_rate_hz_s, double pulse_width_s,
-                        void* d_raw);
+                        void* d_raw, int accumulate);
 
 /* Per pulse and target geometry of the three echo models on the device (fp64): fills the d_tau_pb table (and, for
  * model 2, d_amp_pt) that the sample kernels consume.  All pointers are device pointers.

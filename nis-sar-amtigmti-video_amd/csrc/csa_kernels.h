@@ -91,6 +91,7 @@ struct EchoArgs {
     float2* out;             // [n_pulses][n_samples]
     double kr, t_p, u_off;   // u = t_fast - tau - u_off
     int n_pulses, n_targets, n_samples;
+    int accumulate;          // out += the sum (a second target set into the same pulses) instead of out =
 };
 hipError_t launch_echo_synth(const EchoArgs& a, hipStream_t st);
 struct EchoGeoArgs {

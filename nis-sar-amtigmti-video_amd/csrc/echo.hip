@@ -49,7 +49,11 @@ __global__ __launch_bounds__(ECHO_THREADS) void echo_synth_kernel(EchoArgs a) {
             acc_im = fmaf(gate, e.y, acc_im);
         }
     }
-    if (live) a.out[(size_t)i * a.n_samples + j] = make_float2(acc_re, acc_im);
+    if (live) {
+        cf* o = a.out + (size_t)i * a.n_samples + j;
+        if (a.accumulate) { const cf x = *o; acc_re += x.x; acc_im += x.y; }
+        *o = make_float2(acc_re, acc_im);
+    }
 }
 
 // ------------------------------------------------------------------------------

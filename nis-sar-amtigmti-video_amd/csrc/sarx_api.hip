@@ -586,7 +586,7 @@ int sarx_multilook_dev(sarx_ctx* c, const void* in, float* out, int rows, int co
 }
 
 int sarx_echo_synth_dev(sarx_ctx* c, const double* tau_pb, const float* amp, const double* t_fast, int n_pulses,
-                        int n_targets, int n_samples, double kr, double t_p, void* raw) {
+                        int n_targets, int n_samples, double kr, double t_p, void* raw, int accumulate) {
     NEED_CTX(c);
     if (!tau_pb || !amp || !t_fast || !raw) return fail(c, SARX_ERR_INVALID, "NULL pointer");
     if (n_pulses <= 0 || n_targets <= 0 || n_samples <= 0 || n_pulses > 65535)
@@ -594,6 +594,7 @@ int sarx_echo_synth_dev(sarx_ctx* c, const double* tau_pb, const float* amp, con
     EchoArgs a{};
     a.tau_pb = (const double2*)tau_pb; a.amp = amp; a.t_fast = t_fast; a.out = (float2*)raw;
     a.kr = kr; a.t_p = t_p; a.u_off = 0.5 * t_p; a.n_pulses = n_pulses; a.n_targets = n_targets; a.n_samples = n_samples;
+    a.accumulate = accumulate != 0;
     HIPCHK(c, launch_echo_synth(a, c->stream));
     return SARX_OK;
 }

@@ -83,7 +83,7 @@ SIGNATURES = {
     "sarx_fill_noise_c64": (_i, [_vp, _vp, _sz, _u64]),
     "sarx_add_ocean_noise_dev": (_i, [_vp, _vp, _sz, _d, _d, _d, _u64]),
     "sarx_power_stats_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
-    "sarx_echo_synth_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _vp]),
+    "sarx_echo_synth_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _vp, _i]),
     "sarx_echo_geometry_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _vp, _vp]),
     "sarx_echo_spotlight_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _vp]),
     "sarx_tdbp_plan_create": (_i, [_vp, _i, _i, _i, _i, _P(TdbpParams), _P(_vp)]),

@@ -14,16 +14,16 @@ import numpy as np
 
 from . import radar
 from ._ffi import check
-from .engine import default_context
+from .engine import DeviceArray, default_context
 
 _PULSE_CHUNK = 4096          # bounds the [pulses x targets] fp64 table held on the device per launch
 
 
 def synth_device(ctx, model, tgt_pos, tgt_vel, t_pulse, tx_pos, aux, amp_or_rcs, t_fast_abs, kr, t_p, c_light, fc,
-                 l_ant=0.0, wavelength=0.0, out=None):
+                 l_ant=0.0, wavelength=0.0, out=None, accumulate=False):
     """Geometry kernel + sample kernel, pulse chunk by pulse chunk, entirely on the device.
     model 0/1: amp_or_rcs = sqrt(rcs) per target; model 2 (spotlight): rcs per target (the gain is per pulse).
-    Returns the DeviceBuffer holding raw [n_pulses x n_samples] complex64 (``out`` if given)."""
+    Returns the DeviceBuffer holding raw [n_pulses x n_samples] complex64 (``out`` if given; ``accumulate`` adds to it)."""
     lib = ctx.lib
     n_pulses, n_tgt, n_samp = tx_pos.shape[0], tgt_pos.shape[0], t_fast_abs.size
     d_tp = ctx.to_device(np.ascontiguousarray(tgt_pos, dtype=np.float64))
@@ -54,7 +54,8 @@ def synth_device(ctx, model, tgt_pos, tgt_vel, t_pulse, tx_pos, aux, amp_or_rcs,
         if model == 2:
             check(lib.sarx_echo_spotlight_dev(ctx.h, d_tab.ptr, d_apt.ptr, d_tf.ptr, n, n_tgt, n_samp, float(kr), float(t_p), dst), ctx.h)
         else:
-            check(lib.sarx_echo_synth_dev(ctx.h, d_tab.ptr, d_amp.ptr, d_tf.ptr, n, n_tgt, n_samp, float(kr), float(t_p), dst), ctx.h)
+            check(lib.sarx_echo_synth_dev(ctx.h, d_tab.ptr, d_amp.ptr, d_tf.ptr, n, n_tgt, n_samp, float(kr), float(t_p), dst,
+                                          1 if accumulate else 0), ctx.h)
     ctx.sync()
     for b in (d_tp, d_tv, d_t, d_tx, d_aux, d_tf, d_rcs, d_amp, d_tab, d_apt):
         if b is not None:
@@ -126,9 +127,13 @@ def run_custom_physics(targets, t_vec, pos, tuned_prp, t_p, fc, bw, *, R0=None, 
 
 
 def run_bistatic_physics_gpu(targets, t_vec, pos_tx_np, vel_tx_np, rx_offset_dist, vel_target_np, *, FS=None,
-                             BW=None, T_p=None, R0=None, C=None, FC=None, window_sec=22e-6, ctx=None):
+                             BW=None, T_p=None, R0=None, C=None, FC=None, window_sec=22e-6, ctx=None, device=False,
+                             add_to=None):
     """Bistatic (one Tx, offset Rx) echo of moving point targets; drop-in for
-    sar_ati_dcpa_sim_csa.py:106-181.  returns (raw complex64, t_start_fast)"""
+    sar_ati_dcpa_sim_csa.py:106-181.  returns (raw complex64, t_start_fast).
+    ``device=True`` returns a DeviceArray instead of a NumPy array; ``add_to`` (a DeviceArray of the same shape)
+    receives this call's echoes on top of what it holds - the reference's ``raw += clutter`` (:193-196) - and is
+    returned."""
     k = radar.reference_constants()
     FS, BW, T_p, R0 = (FS or k["FS"]), (BW or k["BW"]), (T_p or k["T_p"]), (R0 or k["R0"])
     C, FC = (C or k["C"]), (FC or k["FC"])
@@ -145,6 +150,14 @@ def run_bistatic_physics_gpu(targets, t_vec, pos_tx_np, vel_tx_np, rx_offset_dis
     v_dir = v_tx / np.linalg.norm(v_tx, axis=1, keepdims=True)      # :145
     p_rx = p_tx + v_dir * rx_offset_dist                             # :148
     # target motion p0 + v t (:151), d_tx, d_rx (:156-157), tau = (d_tx + d_rx) / C, phase -2 pi FC tau (:159-160): geometry kernel
+    if add_to is not None:
+        if add_to.shape != (t_vec.size, num_samples) or add_to.offset:
+            raise ValueError("add_to must be a whole DeviceArray of this call's shape")
+        synth_device(ctx, 1, p0, np.asarray(vel_target_np, dtype=np.float64), t_vec, p_tx, p_rx, amp, t_fast_abs, k_rate, T_p,
+                     C, FC, out=add_to.buf, accumulate=True)
+        return add_to, t_start_fast
     d_raw = synth_device(ctx, 1, p0, np.asarray(vel_target_np, dtype=np.float64), t_vec, p_tx, p_rx, amp, t_fast_abs, k_rate, T_p,
                          C, FC)
+    if device:
+        return DeviceArray(d_raw, (t_vec.size, num_samples)), t_start_fast
     return _download(d_raw, (t_vec.size, num_samples)), t_start_fast

@@ -48,6 +48,38 @@ class DeviceBuffer:
         return out
 
 
+class DeviceArray:
+    """A row-major 2-D complex64 array living in a DeviceBuffer: what the echo generators return with ``device=True``
+    and what the focusers accept in place of a NumPy array, so a scene can go from synthesis to products without
+    visiting the host.  ``rows(a, b)`` is a view (the DPCA pulse shift of sar_ati_dcpa_sim_csa.py:402-403 is two
+    such views)."""
+
+    def __init__(self, buf, shape, offset=0, owner=True):
+        self.buf, self.shape, self.offset, self.owner = buf, (int(shape[0]), int(shape[1])), int(offset), owner
+        self.ctx = buf.ctx
+
+    @property
+    def ptr(self):
+        return self.buf.ptr + self.offset
+
+    @property
+    def nbytes(self):
+        return self.shape[0] * self.shape[1] * 8
+
+    def rows(self, a, b):
+        a, b, _ = slice(a, b).indices(self.shape[0])
+        return DeviceArray(self.buf, (max(b - a, 0), self.shape[1]), self.offset + a * self.shape[1] * 8, owner=False)
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=np.complex64)
+        check(self.ctx.lib.sarx_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes), self.ctx.h)
+        return out
+
+    def release(self):
+        if self.owner:
+            self.buf.release()
+
+
 class Context:
     """sarx_ctx wrapper: one per GPU, owns a compute stream and a comm stream."""
 
@@ -110,7 +142,7 @@ class Context:
 
     def echo_synth(self, d_tau_pb, d_amp, d_t_fast, n_pulses, n_targets, n_samples, kr, t_p, d_raw):
         check(self.lib.sarx_echo_synth_dev(self.h, d_tau_pb.ptr, d_amp.ptr, d_t_fast.ptr, int(n_pulses), int(n_targets),
-                                           int(n_samples), float(kr), float(t_p), d_raw.ptr), self.h)
+                                           int(n_samples), float(kr), float(t_p), d_raw.ptr, 0), self.h)
 
     def corner_turn(self, src, dst, rows, cols):
         check(self.lib.sarx_corner_turn_dev(self.h, src.ptr, dst.ptr, int(rows), int(cols)), self.h)

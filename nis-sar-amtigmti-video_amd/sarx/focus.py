@@ -9,7 +9,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _ffi
-from .engine import CsaPlan, default_context
+from .engine import CsaPlan, DeviceArray, default_context
 
 _plan_cache = {}
 _PLAN_CACHE_MAX = 4
@@ -135,23 +135,35 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
                    ctx=None, pulse_shift=True):
     """The reference script's processing section in one call
     (sar_ati_dcpa_sim_csa.py:402-419,447-449): pulse shift, CSA focus of both
-    channels, ATI/DPCA products.  Images stay on the GPU between the steps."""
+    channels, ATI/DPCA products.  Images stay on the GPU between the steps; with DeviceArray inputs (echo
+    generators called with device=True) nothing is uploaded at all."""
     ctx = ctx or default_context()
-    r1, r2 = (dpca_pulse_shift(raw_rx1, raw_rx2) if pulse_shift else (raw_rx1, raw_rx2))
-    r1 = np.ascontiguousarray(r1, dtype=np.complex64)
-    r2 = np.ascontiguousarray(r2, dtype=np.complex64)
+    on_device = isinstance(raw_rx1, DeviceArray) and isinstance(raw_rx2, DeviceArray)
+    if on_device:                      # echoes synthesised on the GPU: the pulse shift is two views, nothing is uploaded
+        r1, r2 = (raw_rx1.rows(1, None), raw_rx2.rows(0, -1)) if pulse_shift else (raw_rx1, raw_rx2)
+    else:
+        r1, r2 = (dpca_pulse_shift(raw_rx1, raw_rx2) if pulse_shift else (raw_rx1, raw_rx2))
+        r1 = np.ascontiguousarray(r1, dtype=np.complex64)
+        r2 = np.ascontiguousarray(r2, dtype=np.complex64)
+    if r1.shape != r2.shape:
+        raise ValueError("the two channels must have the same shape")
     n_az, n_rg = r1.shape
     args = (center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
             platform_speed_mps, range_ref_m, t_start_fast)
     plan = _get_plan(ctx, n_az, n_rg, args, _ffi.FUSE_RANGE)
     n = n_az * n_rg
-    d_raw = ctx.alloc(n * 8)
     d_s1, d_s2 = ctx.alloc(n * 8), ctx.alloc(n * 8)
-    d_raw.upload(r1)
-    plan.focus_dev(d_raw, d_s1)
-    ctx.sync()
-    d_raw.upload(r2)
-    plan.focus_dev(d_raw, d_s2)
+    if on_device:
+        d_raw = None
+        plan.focus_dev(r1, d_s1)
+        plan.focus_dev(r2, d_s2)
+    else:
+        d_raw = ctx.alloc(n * 8)
+        d_raw.upload(r1)
+        plan.focus_dev(d_raw, d_s1)
+        ctx.sync()
+        d_raw.upload(r2)
+        plan.focus_dev(d_raw, d_s2)
     outs = {k: ctx.alloc(n * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
     max_mag, sum_interf = ctx.ati_dpca(d_s1, d_s2, n, cal_phase, outs)
     thr = np.float32(max_mag) * np.float32(mask_frac)
@@ -164,5 +176,6 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
         res[k] = v.download(np.float32, (n_az, n_rg)).T
     res["ati_phase_masked"] = d_masked.download(np.float32, (n_az, n_rg)).T
     for b in (d_raw, d_s1, d_s2, d_masked, *outs.values()):
-        b.release()
+        if b is not None:
+            b.release()
     return res

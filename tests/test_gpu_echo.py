@@ -70,3 +70,34 @@ def test_many_targets_and_focus_chain():
     img = sarx.sar_focus_csa(raw, *args)[0]
     oimg = orc.sar_focus_csa(ref.astype(np.complex64), *args)[0]
     assert orc.rel_l2(np.abs(img), np.abs(oimg)) < 1e-4
+
+
+def test_device_resident_two_channel_chain():
+    """Echoes synthesised with device=True, a second target set added in place (add_to), the DPCA pulse shift as two
+    views and focus_ati_dpca on DeviceArrays: identical to the same chain through host arrays."""
+    import sarx
+    k = orc.scaled_radar(129, 2048)
+    rng = np.random.default_rng(3)
+    ship = [{"position": [rng.uniform(-10, 10), rng.uniform(-10, 10), 0.0], "rcs": float(rng.uniform(5, 50))} for _ in range(5)]
+    sea = [{"position": [rng.uniform(-30, 30), rng.uniform(-30, 30), 0.0], "rcs": float(rng.uniform(0.1, 2))} for _ in range(300)]
+    t_vec = np.linspace(-64 / k["PRF"], 64 / k["PRF"], 129)
+    pos, vel = orc.orbit_track(t_vec, k)
+    kw = dict(FS=k["FS"], BW=k["BW"], T_p=k["T_p"], R0=k["R0"], FC=k["FC"], window_sec=2048 / k["FS"])    # the 1 us lead-in must fit
+    dev, host = [], []
+    for off in (-1.0, 1.0):
+        d, t0 = sarx.run_bistatic_physics_gpu(ship, t_vec, pos, vel, off, [12.0, 0.0, 0.0], device=True, **kw)
+        same, _ = sarx.run_bistatic_physics_gpu(sea, t_vec, pos, vel, off, [0.0, 0.0, 0.0], add_to=d, **kw)
+        assert same is d and d.shape == (129, 2048)
+        h = (sarx.run_bistatic_physics_gpu(ship, t_vec, pos, vel, off, [12.0, 0.0, 0.0], **kw)[0]
+             + sarx.run_bistatic_physics_gpu(sea, t_vec, pos, vel, off, [0.0, 0.0, 0.0], **kw)[0])
+        assert orc.rel_l2(d.numpy(), h) < 1e-6
+        dev.append(d)
+        host.append(d.numpy())
+    args = (k["Lambda"], k["T_p"], k["Kr"], k["FS"], k["PRF"], k["V_eff"], k["R0"], t0)
+    a = sarx.focus_ati_dpca(dev[0], dev[1], *args)
+    b = sarx.focus_ati_dpca(host[0], host[1], *args)
+    for d in dev:
+        d.release()
+    assert a["slc1"].shape == (2048, 128) and np.abs(a["slc1"]).max() > 0
+    for key in ("slc1", "slc2", "ati_phase", "dpca_mag", "ati_phase_masked"):
+        np.testing.assert_array_equal(a[key], b[key])
