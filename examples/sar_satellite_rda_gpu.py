@@ -44,17 +44,19 @@ def main():
     sim_targets = [dict(t, position=np.asarray(t["position"]) @ rot.T) for t in base]
 
     t0 = time.time()
-    raw_data, t_start, fs_val = sarx.run_physics_engine(sim_targets, pos_sat, t_vec)          # :346
+    d_raw, t_start, fs_val = sarx.run_physics_engine(sim_targets, pos_sat, t_vec, device=True)   # :346, stays on the GPU
     snr_db, gain_db = sarx.calculate_snr_db(R0, 50000.0, Lambda, BW, T_int)                   # :349-350
-    raw_data = sarx.add_ocean_noise(raw_data, snr_db, seed=a.seed)                            # :351
+    sarx.add_ocean_noise(d_raw, snr_db, seed=a.seed)                                          # :351, in place
     t_echo = time.time() - t0
 
     t0 = time.time()
     final_img, r_axis, cross_rng, rc_time_T, rd_map_T, rd_rcmc_T, dop_axis = sarx.sar_focus_rda(
-        raw_data.T, Lambda, T_p, BW / T_p, fs_val, PRF, V_eff, R0)                            # :453-462
+        d_raw.T, Lambda, T_p, BW / T_p, fs_val, PRF, V_eff, R0)                               # :453-462
+    raw_data = d_raw.numpy()                                                                  # the file keeps raw_phist (:484)
+    d_raw.release()
     t_proc = time.time() - t0
     print(f"radar equation: gain {gain_db:.1f} dB, SNR {snr_db:.1f} dB; echo + noise {t_echo:.2f} s, "
-          f"RDA focus {t_proc:.2f} s ({raw_data.shape[0]} x {raw_data.shape[1]}, host<->device copies included)")
+          f"RDA focus {t_proc:.2f} s ({raw_data.shape[0]} x {raw_data.shape[1]}, the echoes are focused where they were synthesised; all seven outputs downloaded)")
     np.savez(a.out, raw_phist=raw_data, range_comp=rc_time_T.T, rd_map=rd_map_T.T, rd_rcmc=rd_rcmc_T.T,
              final_image=final_img, range_axis=r_axis, cross_range=t_vec * V_eff, doppler_axis=dop_axis,
              orbit_alt=k["h"], orbit_vel=k["V_sat"], look_ang=45.0,

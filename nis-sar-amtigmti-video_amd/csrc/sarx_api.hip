@@ -530,6 +530,20 @@ int sarx_rda_focus_host(sarx_rda_plan* p, const void* phist, float* mag, void* p
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SARX_OK;
 }
+int sarx_rda_focus_dev(sarx_rda_plan* p, const void* d_phist, float* mag, void* pc, void* rd, void* rc) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!d_phist || !mag) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    const size_t px = (size_t)p->n_r * p->n_p;
+    HIPCHK(c, rda_focus(p->r, (const float2*)d_phist, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mag, rda_mag(p->r), px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    void* outs[3] = {pc, rd, rc};
+    for (int i = 0; i < 3; ++i)
+        if (outs[i]) HIPCHK(c, hipMemcpyAsync(outs[i], rda_stage(p->r, i), px * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SARX_OK;
+}
 int sarx_rda_axes(const sarx_rda_plan* p, double* range_centered, double* cross_range, double* doppler) {
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
     rda_axes(p->r, range_centered, cross_range, doppler);

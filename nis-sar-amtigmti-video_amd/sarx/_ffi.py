@@ -75,6 +75,7 @@ SIGNATURES = {
     "sarx_rda_plan_create": (_i, [_vp, _i, _i, _P(RadarParams), _P(_vp)]),
     "sarx_rda_plan_destroy": (_i, [_vp]),
     "sarx_rda_focus_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "sarx_rda_focus_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sarx_rda_axes": (_i, [_vp, _vp, _vp, _vp]),
     "sarx_ati_dpca_dev": (_i, [_vp, _vp, _vp, _sz, _d, _P(AtiOutputs), _P(_d), _P(_d)]),
     "sarx_mask_phase_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),

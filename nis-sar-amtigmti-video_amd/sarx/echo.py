@@ -70,7 +70,7 @@ def _download(d_raw, shape):
 
 
 def run_physics_engine(targets, pos_sat, t_vec, *, BW=None, T_p=None, R0=None, C=None, FC=None, fs=600e6,
-                       window_sec=22e-6, ctx=None):
+                       window_sec=22e-6, ctx=None, device=False):
     """Monostatic echo; drop-in for sar_satellite_sim.py:211-305.
     returns (raw [len(t_vec) x N_samples] complex64, t_start_fast, fs)"""
     k = radar.reference_constants()
@@ -86,6 +86,8 @@ def run_physics_engine(targets, pos_sat, t_vec, *, BW=None, T_p=None, R0=None, C
     pos_sat = np.asarray(pos_sat, dtype=np.float64)[: len(t_vec)]
     # ranges, delays tau = 2 d / C and carrier phase -4 pi FC d / C (:268-272) per pulse and target: geometry kernel
     d_raw = synth_device(ctx, 0, t_pos, None, None, pos_sat, None, amp, t_fast_abs, k_rate, T_p, C, FC)
+    if device:                                                      # stays on the GPU for add_ocean_noise / sar_focus_rda
+        return DeviceArray(d_raw, (pos_sat.shape[0], num_samples)), t_start_fast, fs
     return _download(d_raw, (pos_sat.shape[0], num_samples)), t_start_fast, fs
 
 

@@ -54,9 +54,14 @@ class DeviceArray:
     visiting the host.  ``rows(a, b)`` is a view (the DPCA pulse shift of sar_ati_dcpa_sim_csa.py:402-403 is two
     such views)."""
 
-    def __init__(self, buf, shape, offset=0, owner=True):
+    def __init__(self, buf, shape, offset=0, owner=True, transposed=False):
         self.buf, self.shape, self.offset, self.owner = buf, (int(shape[0]), int(shape[1])), int(offset), owner
         self.ctx = buf.ctx
+        self.transposed = transposed       # .T of a row-major array: same memory, shape reversed (like a NumPy view)
+
+    @property
+    def T(self):
+        return DeviceArray(self.buf, self.shape[::-1], self.offset, owner=False, transposed=not self.transposed)
 
     @property
     def ptr(self):
@@ -67,13 +72,15 @@ class DeviceArray:
         return self.shape[0] * self.shape[1] * 8
 
     def rows(self, a, b):
+        if self.transposed:
+            raise ValueError("rows() of a transposed view is not contiguous")
         a, b, _ = slice(a, b).indices(self.shape[0])
         return DeviceArray(self.buf, (max(b - a, 0), self.shape[1]), self.offset + a * self.shape[1] * 8, owner=False)
 
     def numpy(self):
-        out = np.empty(self.shape, dtype=np.complex64)
+        out = np.empty(self.shape[::-1] if self.transposed else self.shape, dtype=np.complex64)
         check(self.ctx.lib.sarx_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes), self.ctx.h)
-        return out
+        return out.T if self.transposed else out
 
     def release(self):
         if self.owner:

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from ._ffi import check
-from .engine import DeviceBuffer, default_context
+from .engine import DeviceArray, DeviceBuffer, default_context
 
 # sar_satellite_sim.py:307-317
 P_TX, ANT_LENGTH, ANT_WIDTH, T_SYS, NF_DB, LOSS_DB, K_BOLTZ, SCR_DB, K_NU = 1000.0, 3.5, 0.5, 290.0, 5.0, 3.0, 1.380649e-23, 10.0, 1.0
@@ -49,6 +49,11 @@ def add_ocean_noise(raw_data, snr_db, scr_db=SCR_DB, k_nu=K_NU, *, seed=0, ctx=N
     """Drop-in for sar_satellite_sim.py:331-344 (noise relative to the MEAN signal power).  A NumPy array is
     returned as a new complex64 array; a DeviceBuffer is modified in place (pass its sample count as
     ``raw_data.nbytes // 8``) and returned."""
+    if isinstance(raw_data, DeviceArray):                           # in place on the GPU, returned
+        n = raw_data.shape[0] * raw_data.shape[1]
+        _, mean = power_stats(raw_data, n, ctx or raw_data.ctx)
+        add_noise_dev(raw_data, n, mean, snr_db, scr_db, k_nu, seed, ctx or raw_data.ctx)
+        return raw_data
     if isinstance(raw_data, DeviceBuffer):
         n = raw_data.nbytes // 8
         _, mean = power_stats(raw_data, n, ctx)

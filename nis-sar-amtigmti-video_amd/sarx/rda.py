@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import check
-from .engine import default_context
+from .engine import DeviceArray, default_context
 
 
 class RdaPlan:
@@ -48,28 +48,39 @@ def _plan(ctx, n_r, n_p, prm):
 
 def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
                   platform_speed_mps, range_grp_m, *, ctx=None, intermediates=True):
-    """phist: [num_ranges x num_pulses] complex (the scripts pass ``raw_data.T``).
+    """phist: [num_ranges x num_pulses] complex (the scripts pass ``raw_data.T``); a NumPy array, or ``d.T`` of the
+    [pulses x ranges] DeviceArray an echo generator returned with ``device=True`` (nothing is uploaded then).
 
     Returns the reference's 7-tuple (:447-448): (sar_image_mag.T [pulses x ranges], range_axis_centered,
     cross_range_m, phist_compressed, range_doppler, range_doppler_rcmc [ranges x pulses each], doppler_freq).
     Images are float32 / complex64.  ``intermediates=False`` skips downloading the three complex maps
     (they come back as None).
     """
-    a = np.asarray(phist)
-    if a.ndim != 2:
-        raise ValueError("phist must be 2-D [num_ranges x num_pulses]")
-    n_r, n_p = a.shape
-    ctx = ctx or default_context()
+    on_device = isinstance(phist, DeviceArray)
+    if on_device:
+        if not phist.transposed:
+            raise ValueError("device input must be raw.T of a [pulses x ranges] DeviceArray, as the scripts pass raw_data.T")
+        n_r, n_p = phist.shape
+        ctx = ctx or phist.ctx
+    else:
+        a = np.asarray(phist)
+        if a.ndim != 2:
+            raise ValueError("phist must be 2-D [num_ranges x num_pulses]")
+        n_r, n_p = a.shape
+        ctx = ctx or default_context()
+        # pulse-major memory: free when phist is the usual raw.T view
+        x = np.ascontiguousarray(a.T, dtype=np.complex64)
     lib = ctx.lib
-    # pulse-major memory: free when phist is the usual raw.T view
-    x = np.ascontiguousarray(a.T, dtype=np.complex64)
     prm = _ffi.RadarParams(center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
                            platform_speed_mps, range_grp_m, 0.0)
     plan = _plan(ctx, n_r, n_p, prm)
     mag = np.empty((n_p, n_r), dtype=np.float32)
     stages = [np.empty((n_p, n_r), dtype=np.complex64) if intermediates else None for _ in range(3)]
     ptr = [s.ctypes.data if s is not None else None for s in stages]
-    check(lib.sarx_rda_focus_host(plan.h, x.ctypes.data, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
+    if on_device:
+        check(lib.sarx_rda_focus_dev(plan.h, phist.ptr, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
+    else:
+        check(lib.sarx_rda_focus_host(plan.h, x.ctypes.data, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
     r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
     check(lib.sarx_rda_axes(plan.h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
     pc, rd, rc = (s.T if s is not None else None for s in stages)

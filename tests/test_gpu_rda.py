@@ -56,6 +56,23 @@ def test_rda_view_input_and_no_intermediates():
     assert rel_l2(out[0], rda.sar_focus_rda(phist, *args)[0]) < TOL
 
 
+def test_rda_device_input_equals_host_input():
+    """sar_focus_rda(d.T, ...) on the DeviceArray of an echo generator = the same call on its NumPy copy."""
+    import sarx
+    phist, args = rda.rda_scene(300, 128, seed=4)
+    raw = np.ascontiguousarray(phist.T)                     # [pulses x ranges], the generators' layout
+    ctx = sarx.default_context()
+    d = sarx.DeviceArray(ctx.to_device(raw), raw.shape)
+    assert d.T.shape == (300, 128) and np.array_equal(d.T.numpy(), raw.T)
+    a = sarx.sar_focus_rda(d.T, *args)
+    b = sarx.sar_focus_rda(raw.T, *args)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    with pytest.raises(ValueError):
+        sarx.sar_focus_rda(d, *args)                        # not the transposed view
+    d.release()
+
+
 def test_rda_errors():
     import sarx
     phist, args = rda.rda_scene(64, 32, seed=1)
