@@ -37,7 +37,8 @@ def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     """Chirp Scaling focus on the GPU; drop-in for the reference function of the
     same name (sar_ati_dcpa_sim_csa.py:202-396).
 
-    phist : [N_pulses x N_samples] complex (any complex/float dtype; computed as complex64)
+    phist : [N_pulses x N_samples] complex (any complex/float dtype; computed as complex64), or the DeviceArray
+            an echo generator returned with ``device=True``
     returns (img.T [N_rg x N_az] complex64, range_axis [N_rg], cross_range_axis [N_az])
 
     Like the reference, the image comes back as the transpose *view* of an
@@ -46,16 +47,29 @@ def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     C-contiguous [N_rg x N_az] array.  ``pulse_width_sec`` is accepted and
     unused, exactly as in the reference.
     """
-    a = np.asarray(phist)
-    if a.ndim != 2:
-        raise ValueError("phist must be 2-D [N_pulses x N_samples]")
+    on_device = isinstance(phist, DeviceArray)          # echoes synthesised with device=True: nothing is uploaded
+    if on_device:
+        if phist.transposed:
+            raise ValueError("a device phist must be the [N_pulses x N_samples] array itself, not its .T")
+        a = phist
+        ctx = ctx or phist.ctx
+    else:
+        a = np.asarray(phist)
+        if a.ndim != 2:
+            raise ValueError("phist must be 2-D [N_pulses x N_samples]")
+        ctx = ctx or default_context()
     n_az, n_rg = a.shape
-    ctx = ctx or default_context()
     flags = (_ffi.FUSE_RANGE if fuse_range else 0) | (_ffi.OUT_RG_MAJOR if materialize_transpose else 0)
     args = (center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
             platform_speed_mps, range_ref_m, t_start_fast)
     plan = _get_plan(ctx, n_az, n_rg, args, flags)
-    img = plan.focus_host(a.astype(np.complex64, copy=False))
+    if on_device:
+        d_img = ctx.alloc(n_az * n_rg * 8)
+        plan.focus_dev(a, d_img)
+        img = d_img.download(np.complex64, (n_rg, n_az) if materialize_transpose else (n_az, n_rg))
+        d_img.release()
+    else:
+        img = plan.focus_host(a.astype(np.complex64, copy=False))
     range_axis, cross_range_axis = plan.axes()
     return (img if materialize_transpose else img.T), range_axis, cross_range_axis
 

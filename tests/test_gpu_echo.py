@@ -94,6 +94,8 @@ def test_device_resident_two_channel_chain():
         dev.append(d)
         host.append(d.numpy())
     args = (k["Lambda"], k["T_p"], k["Kr"], k["FS"], k["PRF"], k["V_eff"], k["R0"], t0)
+    one = sarx.sar_focus_csa(dev[0], *args)[0]               # single channel, device input = host input
+    np.testing.assert_array_equal(one, sarx.sar_focus_csa(host[0], *args)[0])
     a = sarx.focus_ati_dpca(dev[0], dev[1], *args)
     b = sarx.focus_ati_dpca(host[0], host[1], *args)
     for d in dev:
