@@ -94,9 +94,9 @@ int sarx_event_record(sarx_ctx* ctx, int slot);
 int sarx_event_elapsed_ms(sarx_ctx* ctx, int slot_start, int slot_stop, float* out_ms);
 
 /* ---- CSA focus: replaces sar_focus_csa (sar_ati_dcpa_sim_csa.py:202-396) -- */
-/* n_rg in [2, 16384], n_az in [2, 32768].  Powers of two >= 16 run the tuned kernels; any other size (the
+/* n_az, n_rg in [2, 32768].  Powers of two >= 16 run the tuned kernels; any other size (the
  * reference's native 7199 x 13200, :47,111,402) runs chirp-z transforms over them (a non-power-of-two
- * n_az must be <= 16384).  Unsupported sizes fail with SARX_ERR_UNSUPPORTED, never silently. */
+ * n_az must be <= 16384; range lines beyond 16384 samples run as 128 x 256 / 256 x 256 split transforms).  Unsupported sizes fail with SARX_ERR_UNSUPPORTED, never silently. */
 int sarx_csa_plan_create(sarx_ctx* ctx, int n_az, int n_rg, const sarx_radar_params* params,
                          unsigned flags, sarx_plan** out_plan);
 int sarx_csa_plan_destroy(sarx_plan* plan);
@@ -121,7 +121,7 @@ int sarx_csa_plan_bytes(const sarx_plan* plan, uint64_t* out_bytes);
  * params carries the function's positional arguments (range_ref_m = range_grp_m, t_start_fast unused).
  * Images here are [n_pulses x n_ranges] row-major: the memory of the reference's [n_ranges x n_pulses]
  * argument when it is raw.T, and of the returned sar_image_mag.T.  n_ranges + matched-filter taps - 1
- * must be <= 32768; n_pulses <= 32768 (a non-power-of-two n_pulses <= 16384). */
+ * must be <= 65536; n_pulses <= 32768 (a non-power-of-two n_pulses <= 16384). */
 int sarx_rda_plan_create(sarx_ctx* ctx, int n_ranges, int n_pulses, const sarx_radar_params* params,
                          sarx_rda_plan** out_plan);
 int sarx_rda_plan_destroy(sarx_rda_plan* plan);

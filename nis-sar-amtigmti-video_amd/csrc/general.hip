@@ -84,7 +84,8 @@ struct Axis {
     bool direct = false;
     cf *chirp_f = nullptr, *chirp_i = nullptr, *bhat_f = nullptr, *bhat_i = nullptr;   // device
 };
-static const int SPLIT_A = 128, SPLIT_B = 256;       // 32768 = 128 x 256
+static const int SPLIT_B = 256;                       // lines beyond 16384 points: 32768 = 128 x 256, 65536 = 256 x 256
+static inline int split_a(int m) { return m / SPLIT_B; }
 
 static hipError_t upload(const std::vector<zd>& h, cf** d) {
     std::vector<cf> f(h.size());
@@ -114,15 +115,9 @@ static hipError_t axis_init(Axis& ax, int n, int m_max, int direct_max, bool spl
     }
     host_fft(b);
     host_fft(bi);
-    if (m == 32768 && split_order) {   // spectrum order of the split line FFT: position k1*256 + k2 holds bin k1 + 128*k2
-        std::vector<zd> p(m), pi(m);
-        for (int k1 = 0; k1 < SPLIT_A; ++k1)
-            for (int k2 = 0; k2 < SPLIT_B; ++k2) {
-                p[k1 * SPLIT_B + k2] = b[k1 + SPLIT_A * k2];
-                pi[k1 * SPLIT_B + k2] = bi[k1 + SPLIT_A * k2];
-            }
-        b.swap(p);
-        bi.swap(pi);
+    if (m > 16384 && split_order) {    // spectrum order of the split line FFT: position k1*256 + k2 holds bin k1 + (m/256)*k2
+        to_split_order(b);
+        to_split_order(bi);
     }
     hipError_t e;
     if ((e = upload(cf_, &ax.chirp_f)) != hipSuccess) return e;
@@ -153,9 +148,10 @@ static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, h
         a.mulvec = inv ? nullptr : mulvec; a.mul_period = 1;
         return launch_range_pass(m, inv ? RG_IFFT : RG_FFT, a, st);
     }
-    // 32768 = 128 x 256 on the [(rows*128) x 256] view of the lines
+    // 32768 = 128 x 256 (65536 = 256 x 256) on the [(rows*SA) x 256] view of the lines
+    const int SPLIT_A = split_a(m);
     AzArgs z{};
-    z.in = buf; z.out = buf; z.tw_r = g->tw_all + SPLIT_A; z.n_rg = SPLIT_B; z.tw_scale = 1.0f / 32768.0f;
+    z.in = buf; z.out = buf; z.tw_r = g->tw_all + SPLIT_A; z.n_rg = SPLIT_B; z.tw_scale = 1.0f / (float)m;
     z.scale = 1.0f / (float)SPLIT_A;
     z.in_q_stride = SPLIT_A; z.in_m_stride = 1; z.out_q_stride = SPLIT_A; z.out_m_stride = 1;
     a.in = buf; a.out = buf; a.tw = g->tw_all + SPLIT_B; a.inv_n = 1.0f / (float)SPLIT_B; a.n_az = rows * SPLIT_A;
@@ -202,6 +198,7 @@ hipError_t line_fft_pow2(const float2* tw_all, float2* buf, int rows, int m, boo
 void host_fft_pow2(std::vector<zd>& a) { host_fft(a); }
 void to_split_order(std::vector<zd>& a) {
     std::vector<zd> p(a.size());
+    const int SPLIT_A = split_a((int)a.size());
     for (int k1 = 0; k1 < SPLIT_A; ++k1)
         for (int k2 = 0; k2 < SPLIT_B; ++k2) p[k1 * SPLIT_B + k2] = a[k1 + SPLIT_A * k2];
     a.swap(p);
@@ -429,7 +426,7 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     if (l_mf < 1 || n_r < 2 || n_p < 2) { err = "RDA needs n_ranges, n_pulses >= 2 and a positive pulse width"; return nullptr; }
     int m_c = 16;
     while (m_c < n_r + l_mf - 1) m_c <<= 1;
-    if (m_c > 32768) { err = "range samples + matched-filter taps - 1 must be <= 32768"; return nullptr; }
+    if (m_c > 65536) { err = "range samples + matched-filter taps - 1 must be <= 65536"; return nullptr; }
     Rda* r = new Rda();
     r->n_p = n_p; r->n_r = n_r; r->m_c = m_c; r->l_mf = l_mf;
     r->lam = prm->wavelength_m; r->vr = prm->platform_speed_mps; r->prf = prm->prf_hz;
@@ -462,12 +459,7 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     nrm = sqrt(nrm);
     for (int k = 0; k < l_mf; ++k) h[k] /= nrm;
     host_fft(h);
-    if (m_c == 32768) {
-        std::vector<zd> p(m_c);
-        for (int k1 = 0; k1 < SPLIT_A; ++k1)
-            for (int k2 = 0; k2 < SPLIT_B; ++k2) p[k1 * SPLIT_B + k2] = h[k1 + SPLIT_A * k2];
-        h.swap(p);
-    }
+    if (m_c > 16384) to_split_order(h);
     if ((e = upload(h, &r->hhat)) != hipSuccess) return bail("upload filter", e);
     std::vector<zd> win(n_p);
     for (int i = 0; i < n_p; ++i) win[i] = zd(n_p > 1 ? 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(n_p - 1)) : 1.0, 0.0);
@@ -551,7 +543,7 @@ void general_csa_destroy(GeneralCsa* g) {
 }
 
 GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm, const float2* tw_all, std::string& err) {
-    if (n_az < 2 || n_rg < 2 || n_rg > 16384 || n_az > 32768) { err = "n_rg must be in [2, 16384], n_az in [2, 32768]"; return nullptr; }
+    if (n_az < 2 || n_rg < 2 || n_rg > 32768 || n_az > 32768) { err = "sizes must be in [2, 32768]"; return nullptr; }
     GeneralCsa* g = new GeneralCsa();
     g->n_az = n_az; g->n_rg = n_rg; g->p = *prm; g->tw_all = tw_all;
     g->ldc = (n_rg + 31) / 32 * 32;
@@ -565,7 +557,7 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
         if (e == hipErrorInvalidValue) { err = "a non-power-of-two n_az must be <= 16384 (chirp-z length 32768)"; general_csa_destroy(g); return nullptr; }
         return bail("azimuth tables", e);
     }
-    if ((e = axis_init(g->rg, n_rg, 32768, 16384, true)) != hipSuccess) return bail("range tables", e);
+    if ((e = axis_init(g->rg, n_rg, 65536, 16384, true)) != hipSuccess) return bail("range tables", e);
     // migration factors in natural fftfreq order, any parity (sar_ati_dcpa_sim_csa.py:225,244-249,262)
     const double C0 = 299792458.0, lam = prm->wavelength_m, Kr = prm->chirp_rate_hz_s, Vr = prm->platform_speed_mps,
                  Rref = prm->range_ref_m, fa_step = 1.0 / ((double)n_az * (1.0 / prm->prf_hz));

@@ -241,10 +241,10 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
     NEED_CTX(c);
     if (!out || !prm) return fail(c, SARX_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    if (n_az < 2 || n_rg < 2 || n_az > 2 * TW_MAX || n_rg > TW_MAX)
-        return fail(c, SARX_ERR_UNSUPPORTED, "n_az=%d n_rg=%d: n_az must be in [2, %d], n_rg in [2, %d]", n_az, n_rg, 2 * TW_MAX, TW_MAX);
+    if (n_az < 2 || n_rg < 2 || n_az > 2 * TW_MAX || n_rg > 2 * TW_MAX)
+        return fail(c, SARX_ERR_UNSUPPORTED, "n_az=%d n_rg=%d: sizes must be in [2, %d]", n_az, n_rg, 2 * TW_MAX);
     if (flags & ~(SARX_OUT_RG_MAJOR | SARX_FUSE_RANGE)) return fail(c, SARX_ERR_INVALID, "unknown plan flags 0x%x", flags);
-    const bool general = !is_pow2(n_az) || !is_pow2(n_rg) || n_az < 16 || n_rg < 16 || n_az > TW_MAX;
+    const bool general = !is_pow2(n_az) || !is_pow2(n_rg) || n_az < 16 || n_rg < 16 || n_az > TW_MAX || n_rg > TW_MAX;
     if (!(prm->sample_rate_hz > 0) || !(prm->prf_hz > 0) || !(prm->platform_speed_mps > 0) ||
         !(prm->wavelength_m > 0) || prm->chirp_rate_hz_s == 0.0)
         return fail(c, SARX_ERR_INVALID, "radar parameters must be positive (chirp rate non-zero)");
@@ -491,8 +491,8 @@ int sarx_rda_plan_create(sarx_ctx* c, int n_ranges, int n_pulses, const sarx_rad
     NEED_CTX(c);
     if (!out || !prm) return fail(c, SARX_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    if (n_ranges < 2 || n_pulses < 2 || n_ranges > TW_MAX || n_pulses > 2 * TW_MAX)
-        return fail(c, SARX_ERR_UNSUPPORTED, "n_ranges=%d n_pulses=%d: n_ranges must be in [2, %d], n_pulses in [2, %d]", n_ranges, n_pulses, TW_MAX, 2 * TW_MAX);
+    if (n_ranges < 2 || n_pulses < 2 || n_ranges > 2 * TW_MAX || n_pulses > 2 * TW_MAX)
+        return fail(c, SARX_ERR_UNSUPPORTED, "n_ranges=%d n_pulses=%d: sizes must be in [2, %d]", n_ranges, n_pulses, 2 * TW_MAX);
     if (!(prm->sample_rate_hz > 0) || !(prm->prf_hz > 0) || !(prm->platform_speed_mps > 0) || !(prm->wavelength_m > 0) ||
         !(prm->pulse_width_s > 0))
         return fail(c, SARX_ERR_INVALID, "radar parameters must be positive");

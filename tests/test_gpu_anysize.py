@@ -29,6 +29,8 @@ def test_reference_fixture_96x80():
                                        (7199, 48),       # native azimuth extent: chirp-z over 16384 rows
                                        (9001, 40),       # chirp-z over 32768 rows (128 x 256 column transform)
                                        (32768, 32),      # the largest azimuth extent, direct
+                                       (24, 20000),      # chirp-z over a 65536-point line (256 x 256)
+                                       (16, 32768),      # the largest range extent
                                        (1000, 3000)])
 def test_any_size_vs_oracle(n_az, n_rg):
     import sarx

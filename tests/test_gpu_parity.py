@@ -221,7 +221,7 @@ def test_errors_are_loud(sx, ctx):
     with pytest.raises(sx.SarxError):
         sx.CsaPlan(ctx, 1, 64, *orc.focus_args(k))
     with pytest.raises(sx.SarxError):
-        sx.CsaPlan(ctx, 64, 32768, *orc.focus_args(k))
+        sx.CsaPlan(ctx, 64, 40000, *orc.focus_args(k))
     with pytest.raises(ValueError):
         sx.sar_focus_csa(np.zeros(16, np.complex64), *orc.focus_args(k))
     bad = list(orc.focus_args(k))
