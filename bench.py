@@ -218,7 +218,7 @@ def main():
                        "image_layout": "[n_az x n_rg]; img.T returned as a view like the reference",
                        "parallelism": f"frames sharded 1/GPU x{world}" +
                                       (f"; 16x16 multilook + {collective} per step" if collective else "")},
-            "roofline": {"bound": "hbm", "kernel": ("range_fused_wl_kernel<false> (FFT.Phi2.IFFT.Phi3, one HBM round trip)"
+            "roofline": {"bound": "hbm", "kernel": ("range_fused_wl_kernel (FFT.Phi2.IFFT.Phi3, one HBM round trip)"
                                                     if (not a.unfused and n == 16384) else
                                                     "range_pass_kernel<fused>" if not a.unfused else
                                                     "range_pass_v2_kernel<FFT+Phi2>, <IFFT+Phi3>"),
