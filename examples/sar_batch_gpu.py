@@ -5,6 +5,10 @@ back-projection image focused at the target velocity ("mBP") or at rest ("StdBP"
 never leave the GPU between the three steps.
 
     python examples/sar_batch_gpu.py [--frames 46] [--cpi-pulses 2500] [--nx 512] [--headings 0 90 45 135]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/sar_batch_gpu.py ...   # frames f -> rank f mod N
+
+Frames are independent (:303-331), so with N ranks each focuses every N-th frame on its own GPU and the stack is
+reassembled by an all-gather per round (sarx.batch; 2 MiB per frame, through the gloo group).  Rank 0 writes the files.
 
 Writes one <run_id>.npz per (heading, algorithm) with the frame stack the reference animates (:333-337):
 frames [n x ny x nx] complex64, g_max, extent.
@@ -24,7 +28,7 @@ from sarx.targets import generate_destroyer  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=None, help="default: all that fit in 5 s (46)")
+    ap.add_argument("--frames", type=int, default=None, help="default: all that fit in 5 s (46 of 50)")
     ap.add_argument("--cpi-pulses", type=int, default=None, help="default ceil(0.5 s * PRF) = 2500 (:249)")
     ap.add_argument("--nx", type=int, default=512)
     ap.add_argument("--headings", type=float, nargs="*", default=[0, 90, 45, 135])            # :281
@@ -32,6 +36,13 @@ def main():
     ap.add_argument("--outdir", default="batch_output")
     a = ap.parse_args()
     os.makedirs(a.outdir, exist_ok=True)
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    from sarx.batch import LocalStackComm, TorchStackComm, run_batch_host
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     k = sarx.batch_constants()                                        # :12-50
     PRF, Lambda, R0, BW = k["PRF"], k["Lambda"], k["R0"], k["BW"]
@@ -47,35 +58,39 @@ def main():
     base_target = generate_destroyer(center_pos=(0, 0, 0))
     L_ANT = Lambda * R0 / v["swath"]                                  # :297
     snr_db_raw = sarx.calculate_raw_snr_db(R0, 5000.0, Lambda, BW, L_ANT, consts=k)           # :298
-    ctx = sarx.default_context()
+    ctx = sarx.default_context(int(os.environ.get("LOCAL_RANK", "0")) % max(1, sarx.device_count()))
+    frame_ids = [f for f in range(NUM_FRAMES) if f * STEP_PULSES + CPI_PULSES <= TOTAL_PULSES]      # :305-307
     for h in a.headings:
         for algo, focus_tgt in (("mBP", True), ("StdBP", False)):     # :283-286
             run_id = f"{v['name']}_{int(v['speed'])}_{int(h)}_{algo}"
-            frames = []
-            d_raw = None
+            state = {"d_raw": None, "n_sp": 0}
             t0 = time.time()
-            for f in range(NUM_FRAMES):
+
+            def process_frame(f):
                 i0 = f * STEP_PULSES
-                i1 = i0 + CPI_PULSES
-                if i1 > TOTAL_PULSES:
-                    break
-                t_cpi, p_cpi, v_cpi = t_vec_all[i0:i1], pos_sat_all[i0:i1], vel_sat_all[i0:i1]
+                t_cpi, p_cpi, v_cpi = t_vec_all[i0:i0 + CPI_PULSES], pos_sat_all[i0:i0 + CPI_PULSES], vel_sat_all[i0:i0 + CPI_PULSES]
                 d_raw, t_st, n_sp, v_tgt = sarx.run_physics_spotlight(base_target, t_cpi, p_cpi, v_cpi, heading_deg=h,
                                                                       speed=v["speed"], l_ant=L_ANT, consts=k, device=True,
-                                                                      out=d_raw)   # one pulse buffer for all frames
+                                                                      out=state["d_raw"], ctx=ctx)   # one pulse buffer for all frames
+                state["d_raw"], state["n_sp"] = d_raw, n_sp
                 n = len(t_cpi) * n_sp
                 sig_p, _ = sarx.power_stats(d_raw, n)                                          # :313 max |raw|^2
                 sarx.add_noise_dev(d_raw, n, sig_p, snr_db_raw + k["SNR_BOOST_DB"], k["SCR_DB"], k["K_NU"],
                                    seed=a.seed * 100003 + f)                                   # :314
                 vf = v_tgt if focus_tgt else np.zeros(3)
                 img = sarx.tdbp_gpu(d_raw, p_cpi, v_cpi, t_st, n_sp, vel_focus=vf, t_pulses=t_cpi,
-                                    scene_size=v["swath"], nx=a.nx, ny=a.nx, consts=k)        # :318-321
-                frames.append(img.astype(np.complex64))
-            if d_raw is not None:
-                d_raw.release()
+                                    scene_size=v["swath"], nx=a.nx, ny=a.nx, consts=k, ctx=ctx)   # :318-321
+                return img.astype(np.complex64).view(np.float32)                               # stack slot [ny x 2 nx]
+
+            comm = TorchStackComm() if world > 1 else LocalStackComm()
+            stack = np.ascontiguousarray(run_batch_host(frame_ids, world, rank, process_frame, comm)).view(np.complex64)
+            if state["d_raw"] is not None:
+                state["d_raw"].release()
             ctx.sync()
             dt = time.time() - t0
-            stack = np.stack(frames)
+            if rank != 0:
+                continue
+            frames, n_sp, t_cpi = stack, state["n_sp"], t_vec_all[:CPI_PULSES]
             g_max = float(np.abs(stack).max()) or 1.0                 # :336-337
             out = os.path.join(a.outdir, run_id + ".npz")
             np.savez(out, frames=stack, g_max=g_max, extent=np.array([-v["swath"] / 2, v["swath"] / 2] * 2), fps=FPS)

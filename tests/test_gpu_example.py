@@ -62,3 +62,21 @@ def test_batch_tdbp_example(tmp_path):
             assert z["frames"].shape == (2, 128, 128) and np.isfinite(z["frames"]).all()
             peaks[algo] = float(z["g_max"])
     assert peaks["mBP"] > 1.2 * peaks["StdBP"]
+
+
+def test_batch_tdbp_example_two_ranks_equals_one(tmp_path):
+    """The same batch sharded over 2 ranks (frame f -> rank f mod 2, stack reassembled by the per-round all-gather)
+    writes the same stack as one rank: same kernels, same per-frame seeds."""
+    common = ["--frames", "3", "--cpi-pulses", "600", "--nx", "64", "--headings", "90"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "sar_batch_gpu.py"), *common, "--outdir", str(one)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "examples", "sar_batch_gpu.py"), *common,
+                        "--outdir", str(two)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for algo in ("mBP", "StdBP"):
+        with np.load(one / f"Destroyer_15_90_{algo}.npz") as a, np.load(two / f"Destroyer_15_90_{algo}.npz") as b:
+            assert a["frames"].shape == (3, 64, 64)
+            np.testing.assert_array_equal(a["frames"], b["frames"])
