@@ -9,7 +9,9 @@
 
 namespace sarx {
 struct GeneralCsa;
-GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm, const float2* tw_all, std::string& err);
+// csa_tables: also build the per-row range-convolution spectra the CSA path uses when n_rg is not a power of two
+GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm, const float2* tw_all, std::string& err,
+                               bool csa_tables = true);
 void general_csa_destroy(GeneralCsa* g);
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st);
 uint64_t general_csa_bytes(const GeneralCsa* g);

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <vector>
 
 #include "fft_core.hpp"
@@ -135,17 +136,20 @@ struct GeneralCsa {
     double2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr;
     cf *data = nullptr, *work_a = nullptr, *work_b = nullptr;
     size_t work_elems = 0;
+    cf* ktab = nullptr;          // [n_az x rg.m]: spectrum of the range convolution kernel IFFT_N(Phi_2) per azimuth bin (see below)
     uint64_t bytes = 0;
 };
 
 // ---- power-of-two transforms on work arrays ---------------------------------------------------------
-// mulvec (forward only): the m-point spectrum is multiplied by mulvec[k] (device order at 32768) on the way out
-static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, hipStream_t st, const cf* mulvec = nullptr) {
+// mulvec (forward only): the m-point spectrum is multiplied by mulvec[k] (device order beyond 16384) on the way out;
+// mul_rows > 0: mulvec is a [mul_rows x m] table, one spectrum per line (line r uses row r mod mul_rows)
+static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, hipStream_t st, const cf* mulvec = nullptr,
+                            int mul_rows = 0) {
     RangeArgs a{};
     hipError_t e;
     if (m <= 16384) {
         a.in = buf; a.out = buf; a.tw = g->tw_all + m; a.inv_n = 1.0f / (float)m; a.n_az = rows;
-        a.mulvec = inv ? nullptr : mulvec; a.mul_period = 1;
+        a.mulvec = inv ? nullptr : mulvec; a.mul_period = mul_rows > 0 ? mul_rows : 1;
         return launch_range_pass(m, inv ? RG_IFFT : RG_FFT, a, st);
     }
     // 32768 = 128 x 256 (65536 = 256 x 256) on the [(rows*SA) x 256] view of the lines
@@ -157,7 +161,7 @@ static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, h
     a.in = buf; a.out = buf; a.tw = g->tw_all + SPLIT_B; a.inv_n = 1.0f / (float)SPLIT_B; a.n_az = rows * SPLIT_A;
     if (!inv) {
         if ((e = launch_az_tile(SPLIT_A, 32, false, AZ_EPI_TWCOL, z, rows, st)) != hipSuccess) return e;
-        a.mulvec = mulvec; a.mul_period = SPLIT_A;          // line L = row*128 + k1 holds positions k1*256 + k2
+        a.mulvec = mulvec; a.mul_period = (mul_rows > 0 ? mul_rows : 1) * SPLIT_A;   // line L = row*SA + k1 holds positions k1*256 + k2
         return launch_range_pass(SPLIT_B, RG_FFT, a, st);
     }
     if ((e = launch_range_pass(SPLIT_B, RG_IFFT, a, st)) != hipSuccess) return e;
@@ -262,7 +266,7 @@ template <int WHICH> __global__ __launch_bounds__(256) void bridge_kernel(Bridge
             if (WHICH == 1) { const double d = tau - c.y; p = c.x * d * d; }                          // :272
             else if (WHICH == 2) p = f * fma(c.x, f, c.y);                                            // :318-324
             else { const double d = tau - a.t0; p = fma(c.x, tau, c.y * d * d); }                     // :359,375-380
-            x = cmul(cmul(a.in[(size_t)i * a.in_ld + j], cv), cis_rev(p));
+            x = cmul(a.in ? cmul(a.in[(size_t)i * a.in_ld + j], cv) : cv, cis_rev(p));
             if (a.row_vec) x = cmul(x, a.row_vec[i]);
         }
         a.out[(size_t)i * a.out_ld + j] = x;
@@ -301,6 +305,39 @@ static hipError_t rows_core(GeneralCsa* g, cf* w, bool inv, hipStream_t st) {
     return rows_pow2(g, w, g->n_az, ax.m, true, st);
 }
 
+// ---- range FFT . Phi_2 . IFFT as ONE convolution (range extent not a power of two) ---------------------------------
+// FFT_N, * Phi_2, IFFT_N along a line is the circular convolution of the line with phi_i = IFFT_N(Phi_2[i, :]).  Two chirp-z
+// transforms would cost four M-point FFTs per line; the convolution itself needs two: pad the line to M >= 2N - 1, FFT_M,
+// multiply by K_i = FFT_M(g_i) with g_i[lag mod M] = phi_i[lag mod N] for lags -(N-1)..N-1, IFFT_M, keep N samples.  K is a
+// [n_az x M] table built once per plan with the chirp-z machinery itself (1.9 GB for 7199 x 13200; read in the forward
+// transform's epilogue).
+__global__ __launch_bounds__(256) void kext_kernel(const cf* phi, size_t phi_ld, const cf* chirp, float scale, int n, int m, int rows, cf* out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    int idx = -1;
+    if (j < n) idx = j;                              // lags 0 .. N-1
+    else if (j >= m - n + 1) idx = j - m + n;        // lags -(N-1) .. -1  ->  phi[lag + N]
+    cf w = make_float2(0.f, 0.f);
+    if (idx >= 0) { const cf c = chirp[idx]; w = make_float2(c.x * scale, c.y * scale); }
+    for (int r = blockIdx.y; r < rows; r += gridDim.y)
+        out[(size_t)r * m + j] = idx >= 0 ? cmul(phi[(size_t)r * phi_ld + idx], w) : make_float2(0.f, 0.f);
+}
+
+static hipError_t build_range_kernel_table(GeneralCsa* g, hipStream_t st) {
+    const Axis& rg = g->rg;
+    const int n_az = g->n_az, n_rg = g->n_rg, m = rg.m;
+    cf* lines = g->work_a;
+    // Phi_2 * pre-chirp of the inverse chirp-z, padded; inverse core; post-chirp / N and the lag layout; FFT_M
+    GCK(bridge<2>(g, nullptr, 0, lines, m, n_az, m, nullptr, rg.chirp_i, 1.0f, st));
+    GCK(rows_pow2(g, lines, n_az, m, false, st, rg.bhat_i));
+    GCK(rows_pow2(g, lines, n_az, m, true, st));
+    dim3 grid((m + 255) / 256, n_az < 16384 ? n_az : 16384);
+    hipLaunchKernelGGL(kext_kernel, grid, dim3(256), 0, st, lines, (size_t)m, rg.chirp_i, 1.0f / (float)n_rg, n_rg, m, n_az, g->ktab);
+    GCK(hipGetLastError());
+    GCK(rows_pow2(g, g->ktab, n_az, m, false, st));
+    return hipStreamSynchronize(st);
+}
+
 // sar_focus_csa (:233-385) at any size.  Buffers: wa/wb [m_az x ldc] for the column transforms, work_a doubles as
 // the [n_az x m_rg] line-transform array when the range axis is not a power of two (else the dense image `data`).
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st) {
@@ -315,16 +352,25 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
     cf *first = az.direct ? wa : wb, *other = az.direct ? wb : wa, *res = nullptr;
     GCK(scale_copy(d_in, n_az, n_rg, n_rg, first, az.m, ld, ld, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
     GCK(cols_core(g, first, other, false, st, &res));
-    // * azimuth post-chirp * Phi_1 (:272-274) * range pre-chirp, into the line array
-    GCK(bridge<1>(g, res, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, rg.direct ? nullptr : rg.chirp_f,
-                  1.0f, st));
-    GCK(rows_core(g, lines, false, st));                                              // :278
-    // post-chirp of the forward and pre-chirp of the inverse are conjugates: only Phi_2 (:318-326) and the zero padding remain
-    GCK(bridge<2>(g, lines, lines_ld, lines, lines_ld, n_az, lines_cols, nullptr, nullptr, 1.0f, st));
-    GCK(rows_core(g, lines, true, st));                                               // :331
-    // * range post-chirp / n_rg * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a may hold the lines)
-    GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, rg.direct ? nullptr : rg.chirp_i,
-                  rg.direct ? 1.0f : 1.0f / (float)n_rg, st));
+    if (g->ktab) {
+        // * azimuth post-chirp * Phi_1 (:272-274), zero-padded lines; range FFT . Phi_2 . IFFT (:278-331) as one convolution
+        GCK(bridge<1>(g, res, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
+        GCK(rows_pow2(g, lines, n_az, rg.m, false, st, g->ktab, n_az));
+        GCK(rows_pow2(g, lines, n_az, rg.m, true, st));
+        // * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a holds the lines)
+        GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, nullptr, 1.0f, st));
+    } else {
+        // * azimuth post-chirp * Phi_1 (:272-274) * range pre-chirp, into the line array
+        GCK(bridge<1>(g, res, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, rg.direct ? nullptr : rg.chirp_f,
+                      1.0f, st));
+        GCK(rows_core(g, lines, false, st));                                              // :278
+        // post-chirp of the forward and pre-chirp of the inverse are conjugates: only Phi_2 (:318-326) and the zero padding remain
+        GCK(bridge<2>(g, lines, lines_ld, lines, lines_ld, n_az, lines_cols, nullptr, nullptr, 1.0f, st));
+        GCK(rows_core(g, lines, true, st));                                               // :331
+        // * range post-chirp / n_rg * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a may hold the lines)
+        GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, rg.direct ? nullptr : rg.chirp_i,
+                      rg.direct ? 1.0f : 1.0f / (float)n_rg, st));
+    }
     GCK(cols_core(g, wb, wa, true, st, &res));                                        // :385
     return scale_copy(res, n_az, n_rg, ld, d_out, n_az, n_rg, n_rg, nullptr, nullptr, az.direct ? 1.0f : 1.0f / (float)n_az, st, 0,
                       az.direct ? nullptr : az.chirp_i);
@@ -430,7 +476,7 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     Rda* r = new Rda();
     r->n_p = n_p; r->n_r = n_r; r->m_c = m_c; r->l_mf = l_mf;
     r->lam = prm->wavelength_m; r->vr = prm->platform_speed_mps; r->prf = prm->prf_hz;
-    r->g = general_csa_create(n_p, n_r, prm, tw_all, err);
+    r->g = general_csa_create(n_p, n_r, prm, tw_all, err, false);      // buffers and the azimuth axis only
     if (!r->g) { delete r; return nullptr; }
     auto bail = [&](const char* what, hipError_t e) {
         err = std::string(what) + ": " + hipGetErrorString(e);
@@ -538,11 +584,12 @@ void general_csa_destroy(GeneralCsa* g) {
     if (!g) return;
     axis_free(g->az); axis_free(g->rg);
     hipFree(g->c1); hipFree(g->c2); hipFree(g->c3);
-    hipFree(g->data); hipFree(g->work_a); hipFree(g->work_b);
+    hipFree(g->data); hipFree(g->work_a); hipFree(g->work_b); hipFree(g->ktab);
     delete g;
 }
 
-GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm, const float2* tw_all, std::string& err) {
+GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm, const float2* tw_all, std::string& err,
+                               bool csa_tables) {
     if (n_az < 2 || n_rg < 2 || n_rg > 32768 || n_az > 32768) { err = "sizes must be in [2, 32768]"; return nullptr; }
     GeneralCsa* g = new GeneralCsa();
     g->n_az = n_az; g->n_rg = n_rg; g->p = *prm; g->tw_all = tw_all;
@@ -584,6 +631,13 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
     if ((e = hipMalloc(&g->work_a, g->work_elems * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
     if ((e = hipMalloc(&g->work_b, g->work_elems * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
     g->bytes = ((size_t)n_az * n_rg + 2 * g->work_elems) * sizeof(cf) + 3 * tb;
+    // range FFT . Phi_2 . IFFT as one convolution: per-row kernel spectra (SARX_GENERAL_KTAB=0 keeps the two chirp-z transforms)
+    const char* ev = getenv("SARX_GENERAL_KTAB");
+    if (csa_tables && !g->rg.direct && !(ev && atoi(ev) == 0)) {
+        if ((e = hipMalloc(&g->ktab, rows_work * sizeof(cf))) != hipSuccess) return bail("hipMalloc kernel table", e);
+        if ((e = build_range_kernel_table(g, nullptr)) != hipSuccess) return bail("range kernel table", e);
+        g->bytes += rows_work * sizeof(cf);
+    }
     return g;
 }
 
