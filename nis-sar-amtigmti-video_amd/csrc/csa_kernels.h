@@ -10,7 +10,9 @@ enum RangeMode { RG_FFT = 0, RG_IFFT = 1, RG_FFT_PHI2 = 2, RG_IFFT_PHI3 = 3, RG_
 enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_SCALE = 3,
                   AZ_EPI_TWCOL = 4,      // * W_M^(col*m_out), M = 1/tw_scale (32768-point line split, forward)
                   AZ_EPI_PROCOL = 5,     // inputs * W_M^(col*m_in) first, outputs * scale (its inverse)
-                  AZ_EPI_ROWVEC = 6 };   // * rowvec[output row] (Bluestein filter spectrum fused into the forward transform)
+                  AZ_EPI_ROWVEC = 6,     // * rowvec[output row] (Bluestein filter spectrum fused into the forward transform)
+                  AZ_EPI_TWIDDLE_PADIN = 7,   // inputs from a smaller [io_rows x io_cols] array (ld io_ld), zero outside, * rowvec[input row]; then TWIDDLE
+                  AZ_EPI_CROPOUT = 8 };       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
 
 struct RangeArgs {
     const float2* in;
@@ -34,7 +36,9 @@ struct AzArgs {
     const float2* tw_r;   // exp(-2 pi i m / R), m < R      (in-tile FFT)
     const float2* tw_n;   // exp(-2 pi i m / n_az), m < n_az (four-step twiddle)
     const double2* c1;    // per azimuth bin: {-0.5 Kr Cs, tau_ref}
-    const float2* rowvec; // AZ_EPI_ROWVEC: per output row
+    const float2* rowvec; // AZ_EPI_ROWVEC / CROPOUT: per output row; TWIDDLE_PADIN: per input row (optional)
+    size_t io_ld;         // TWIDDLE_PADIN / CROPOUT: leading dimension and extents of the smaller array
+    int io_rows, io_cols;
     double dt, t_start;
     float scale;          // 1/n_az for the inverse's last step
     float tw_scale;       // 1/M for the column-indexed twiddles of the 32768-point line split

@@ -208,7 +208,16 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
         for (int r = 0; r < R0; ++r) {
             const int mi = E::in_index(t, b, r);
             const size_t rowi = in_base + (size_t)mi * a.in_m_stride;
-            cf x = a.in[rowi * a.n_rg + col];
+            cf x;
+            if constexpr (EPI == AZ_EPI_TWIDDLE_PADIN) {   // copy-in, zero padding and pre-chirp of general.hip fused into the first step
+                x = make_float2(0.f, 0.f);
+                if (rowi < (size_t)a.io_rows && col < a.io_cols) {
+                    x = a.in[rowi * a.io_ld + col];
+                    if (a.rowvec) x = cmul(x, a.rowvec[rowi]);
+                }
+            } else {
+                x = a.in[rowi * a.n_rg + col];
+            }
             if constexpr (EPI == AZ_EPI_PROCOL) {      // inverse of the 32768-point line split: W_M^(+-col*m_in) first
                 const float rev = (float)(col * mi) * a.tw_scale;
                 x = cmul(x, cis_frac(INV ? rev : -rev));
@@ -224,7 +233,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             const int m = E::out_index(t, b, r);
             const size_t rowo = out_base + (size_t)m * a.out_m_stride;
             cf x = v[b * RL + r];
-            if constexpr (EPI == AZ_EPI_TWIDDLE) {
+            if constexpr (EPI == AZ_EPI_TWIDDLE || EPI == AZ_EPI_TWIDDLE_PADIN) {
                 // four-step twiddle W_n^(q*m): q*m < n_az <= 2^14 and 1/n_az is a power of two, so the
                 // argument is exact in fp32 (HW sine/cosine take revolutions; no table load in this pass)
 #if SARX_HW_TWIDDLE
@@ -241,6 +250,13 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                 x.x *= a.scale; x.y *= a.scale;
             } else if constexpr (EPI == AZ_EPI_ROWVEC) {
                 x = cmul(x, a.rowvec[rowo]);
+            } else if constexpr (EPI == AZ_EPI_CROPOUT) {  // post-chirp, scale and crop of general.hip fused into the last step
+                if (rowo < (size_t)a.io_rows && col < a.io_cols) {
+                    x.x *= a.scale; x.y *= a.scale;
+                    if (a.rowvec) x = cmul(x, a.rowvec[rowo]);
+                    a.out[rowo * a.io_ld + col] = x;
+                }
+                continue;
             } else if constexpr (EPI == AZ_EPI_TWCOL) {    // 32768-point line as 128 x 256: twiddle W_M^(+-col*m)
                 const float rev = (float)(col * m) * a.tw_scale;
                 x = cmul(x, cis_frac(INV ? rev : -rev));
@@ -263,6 +279,7 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_PHI1: return launch_az_one<R, W, false, AZ_EPI_PHI1>(a, nq, st);
             case AZ_EPI_TWCOL: return launch_az_one<R, W, false, AZ_EPI_TWCOL>(a, nq, st);
             case AZ_EPI_ROWVEC: return launch_az_one<R, W, false, AZ_EPI_ROWVEC>(a, nq, st);
+            case AZ_EPI_TWIDDLE_PADIN: return launch_az_one<R, W, false, AZ_EPI_TWIDDLE_PADIN>(a, nq, st);
         }
     } else {
         switch (epi) {
@@ -270,6 +287,7 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_TWIDDLE: return launch_az_one<R, W, true, AZ_EPI_TWIDDLE>(a, nq, st);
             case AZ_EPI_SCALE: return launch_az_one<R, W, true, AZ_EPI_SCALE>(a, nq, st);
             case AZ_EPI_PROCOL: return launch_az_one<R, W, true, AZ_EPI_PROCOL>(a, nq, st);
+            case AZ_EPI_CROPOUT: return launch_az_one<R, W, true, AZ_EPI_CROPOUT>(a, nq, st);
         }
     }
     return hipErrorInvalidValue;

@@ -169,8 +169,15 @@ static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, h
 }
 
 // column FFT of length n (power of two, 16..16384) on a [n x ld] array, ld a multiple of 32; in -> out via tmp
+// Optional fused ends of a two-step column transform (n > 128): the first step reads a smaller dense array (zero
+// outside it, times a per-row vector) instead of `in`; the last step of an inverse writes times a per-row vector and a
+// scale into a smaller dense array instead of `out`.  One HBM pass each instead of a separate copy.
+struct ColsSrc { const cf* p; size_t ld; int rows, cols; const cf* rowvec; };
+struct ColsDst { cf* p; size_t ld; int rows, cols; const cf* rowvec; float scale; };
+static bool cols_two_step(int n) { return n > 128; }
+
 static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n, int ld, bool inv, hipStream_t st,
-                            const cf* rowvec = nullptr) {
+                            const cf* rowvec = nullptr, const ColsSrc* src = nullptr, const ColsDst* dst = nullptr) {
     int l2 = 0;
     while ((1 << l2) < n) ++l2;
     const int S = (n <= 128) ? n : (1 << (l2 / 2)), RA = n / S;
@@ -187,10 +194,22 @@ static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n
     }
     a.in = in; a.out = tmp; a.tw_r = g->tw_all + RA;
     a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
-    hipError_t e = launch_az_tile(RA, 32, inv, AZ_EPI_TWIDDLE, a, S, st);
+    int epi_first = AZ_EPI_TWIDDLE;
+    if (src) {
+        if (inv) return hipErrorInvalidValue;
+        epi_first = AZ_EPI_TWIDDLE_PADIN;
+        a.in = src->p; a.io_ld = src->ld; a.io_rows = src->rows; a.io_cols = src->cols; a.rowvec = src->rowvec;
+    }
+    hipError_t e = launch_az_tile(RA, 32, inv, epi_first, a, S, st);
     if (e != hipSuccess) return e;
-    a.in = tmp; a.out = out; a.tw_r = g->tw_all + S;
+    a.in = tmp; a.out = out; a.tw_r = g->tw_all + S; a.rowvec = rowvec;
     a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
+    if (dst) {
+        if (!inv) return hipErrorInvalidValue;
+        a.out = dst->p; a.io_ld = dst->ld; a.io_rows = dst->rows; a.io_cols = dst->cols; a.rowvec = dst->rowvec;
+        a.scale = dst->scale / (float)n;
+        return launch_az_tile(S, 32, true, AZ_EPI_CROPOUT, a, RA, st);
+    }
     return launch_az_tile(S, 32, inv, epi_last, a, RA, st);
 }
 
@@ -290,12 +309,14 @@ static hipError_t bridge(GeneralCsa* g, const cf* in, size_t in_ld, cf* out, siz
 
 // column transform of x [m_az x ldc] (already chirped and padded when the axis is not direct); x and y are both
 // overwritten; returns the buffer holding the result through *res
-static hipError_t cols_core(GeneralCsa* g, cf* x, cf* y, bool inv, hipStream_t st, cf** res) {
+// src: the transform's input comes from there (x is then scratch only); dst: an inverse writes its result there (*res = null)
+static hipError_t cols_core(GeneralCsa* g, cf* x, cf* y, bool inv, hipStream_t st, cf** res, const ColsSrc* src = nullptr,
+                            const ColsDst* dst = nullptr) {
     const Axis& ax = g->az;
-    if (ax.direct) { *res = y; return cols_pow2(g, x, x, y, g->n_az, g->ldc, inv, st); }
-    *res = x;
-    GCK(cols_pow2(g, x, x, y, ax.m, g->ldc, false, st, inv ? ax.bhat_i : ax.bhat_f));     // * filter spectrum in the epilogue
-    return cols_pow2(g, y, y, x, ax.m, g->ldc, true, st);
+    if (ax.direct) { *res = dst ? nullptr : y; return cols_pow2(g, x, x, y, g->n_az, g->ldc, inv, st, nullptr, src, dst); }
+    *res = dst ? nullptr : x;
+    GCK(cols_pow2(g, x, x, y, ax.m, g->ldc, false, st, inv ? ax.bhat_i : ax.bhat_f, src));     // * filter spectrum in the epilogue
+    return cols_pow2(g, y, y, x, ax.m, g->ldc, true, st, nullptr, nullptr, dst);
 }
 // line transform in place on w [n_az x m_rg] (chirped and padded when the axis is not direct)
 static hipError_t rows_core(GeneralCsa* g, cf* w, bool inv, hipStream_t st) {
@@ -350,8 +371,14 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
     // azimuth FFT (:233): d_in -> (chirp, pad) -> wb
     // (the result must land in wb: work_a may become the line array next)
     cf *first = az.direct ? wa : wb, *other = az.direct ? wb : wa, *res = nullptr;
-    GCK(scale_copy(d_in, n_az, n_rg, n_rg, first, az.m, ld, ld, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
-    GCK(cols_core(g, first, other, false, st, &res));
+    const bool fused_ends = cols_two_step(az.m);             // copy-in / copy-out folded into the first / last tile launch
+    if (fused_ends) {
+        const ColsSrc src{d_in, (size_t)n_rg, n_az, n_rg, az.direct ? nullptr : az.chirp_f};
+        GCK(cols_core(g, first, other, false, st, &res, &src));
+    } else {
+        GCK(scale_copy(d_in, n_az, n_rg, n_rg, first, az.m, ld, ld, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
+        GCK(cols_core(g, first, other, false, st, &res));
+    }
     if (g->ktab) {
         // * azimuth post-chirp * Phi_1 (:272-274), zero-padded lines; range FFT . Phi_2 . IFFT (:278-331) as one convolution
         GCK(bridge<1>(g, res, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
@@ -370,6 +397,10 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
         // * range post-chirp / n_rg * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a may hold the lines)
         GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, rg.direct ? nullptr : rg.chirp_i,
                       rg.direct ? 1.0f : 1.0f / (float)n_rg, st));
+    }
+    if (fused_ends) {                                                                 // :385, post-chirp / n_az and crop in the last launch
+        const ColsDst dst{d_out, (size_t)n_rg, n_az, n_rg, az.direct ? nullptr : az.chirp_i, az.direct ? 1.0f : 1.0f / (float)n_az};
+        return cols_core(g, wb, wa, true, st, &res, nullptr, &dst);
     }
     GCK(cols_core(g, wb, wa, true, st, &res));                                        // :385
     return scale_copy(res, n_az, n_rg, ld, d_out, n_az, n_rg, n_rg, nullptr, nullptr, az.direct ? 1.0f : 1.0f / (float)n_az, st, 0,
