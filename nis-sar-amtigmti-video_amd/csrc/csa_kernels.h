@@ -39,6 +39,7 @@ struct AzArgs {
     const float2* rowvec; // AZ_EPI_ROWVEC / CROPOUT: per output row; TWIDDLE_PADIN: per input row (optional)
     size_t io_ld;         // TWIDDLE_PADIN / CROPOUT: leading dimension and extents of the smaller array
     int io_rows, io_cols;
+    int valid_len;        // TWCOL / PROCOL (split lines): only the first valid_len samples of a line are read (rest = 0) / written; 0 = all
     double dt, t_start;
     float scale;          // 1/n_az for the inverse's last step
     float tw_scale;       // 1/M for the column-indexed twiddles of the 32768-point line split

@@ -215,6 +215,8 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                     x = a.in[rowi * a.io_ld + col];
                     if (a.rowvec) x = cmul(x, a.rowvec[rowi]);
                 }
+            } else if constexpr (EPI == AZ_EPI_TWCOL) {   // zero-padded line: the padding is not stored, let alone read
+                x = (a.valid_len && mi * a.n_rg + col >= a.valid_len) ? make_float2(0.f, 0.f) : a.in[rowi * a.n_rg + col];
             } else {
                 x = a.in[rowi * a.n_rg + col];
             }
@@ -247,6 +249,9 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             } else if constexpr (EPI == AZ_EPI_PHI1) {
                 x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
             } else if constexpr (EPI == AZ_EPI_SCALE || EPI == AZ_EPI_PROCOL) {
+                if constexpr (EPI == AZ_EPI_PROCOL) {      // only the cropped part of the line is wanted
+                    if (a.valid_len && m * a.n_rg + col >= a.valid_len) continue;
+                }
                 x.x *= a.scale; x.y *= a.scale;
             } else if constexpr (EPI == AZ_EPI_ROWVEC) {
                 x = cmul(x, a.rowvec[rowo]);

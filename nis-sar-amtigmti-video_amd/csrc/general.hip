@@ -143,8 +143,10 @@ struct GeneralCsa {
 // ---- power-of-two transforms on work arrays ---------------------------------------------------------
 // mulvec (forward only): the m-point spectrum is multiplied by mulvec[k] (device order beyond 16384) on the way out;
 // mul_rows > 0: mulvec is a [mul_rows x m] table, one spectrum per line (line r uses row r mod mul_rows)
+// valid_len > 0 (m > 16384 only): forward reads only the first valid_len samples of each line (the rest are zeros that
+// need not exist in memory), inverse writes only those
 static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, hipStream_t st, const cf* mulvec = nullptr,
-                            int mul_rows = 0) {
+                            int mul_rows = 0, int valid_len = 0) {
     RangeArgs a{};
     hipError_t e;
     if (m <= 16384) {
@@ -158,6 +160,7 @@ static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, h
     z.in = buf; z.out = buf; z.tw_r = g->tw_all + SPLIT_A; z.n_rg = SPLIT_B; z.tw_scale = 1.0f / (float)m;
     z.scale = 1.0f / (float)SPLIT_A;
     z.in_q_stride = SPLIT_A; z.in_m_stride = 1; z.out_q_stride = SPLIT_A; z.out_m_stride = 1;
+    z.valid_len = valid_len;
     a.in = buf; a.out = buf; a.tw = g->tw_all + SPLIT_B; a.inv_n = 1.0f / (float)SPLIT_B; a.n_az = rows * SPLIT_A;
     if (!inv) {
         if ((e = launch_az_tile(SPLIT_A, 32, false, AZ_EPI_TWCOL, z, rows, st)) != hipSuccess) return e;
@@ -381,9 +384,10 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
     }
     if (g->ktab) {
         // * azimuth post-chirp * Phi_1 (:272-274), zero-padded lines; range FFT . Phi_2 . IFFT (:278-331) as one convolution
-        GCK(bridge<1>(g, res, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
-        GCK(rows_pow2(g, lines, n_az, rg.m, false, st, g->ktab, n_az));
-        GCK(rows_pow2(g, lines, n_az, rg.m, true, st));
+        const int vlen = rg.m > 16384 ? n_rg : 0;       // split lines: the zero padding is neither written nor read
+        GCK(bridge<1>(g, res, ld, lines, lines_ld, n_az, vlen ? n_rg : lines_cols, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
+        GCK(rows_pow2(g, lines, n_az, rg.m, false, st, g->ktab, n_az, vlen));
+        GCK(rows_pow2(g, lines, n_az, rg.m, true, st, nullptr, 0, vlen));
         // * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a holds the lines)
         GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, nullptr, 1.0f, st));
     } else {
@@ -571,9 +575,11 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st) {
     const int n_p = r->n_p, n_r = r->n_r, m = r->m_c;
     cf* w = g->work_a;
     // 1 range compression
-    GCK(scale_copy(d_in, n_p, n_r, n_r, w, n_p, m, m, nullptr, nullptr, 1.0f, st));
-    GCK(rows_pow2(g, w, n_p, m, false, st, r->hhat));            // * filter spectrum in the epilogue
-    GCK(rows_pow2(g, w, n_p, m, true, st));
+    // split lines (m > 16384): the zero padding is neither written nor read, and only the 'same' window is written back
+    const int vin = m > 16384 ? n_r : 0, vout = m > 16384 ? (r->l_mf - 1) / 2 + n_r : 0;
+    GCK(scale_copy(d_in, n_p, n_r, n_r, w, n_p, vin ? n_r : m, m, nullptr, nullptr, 1.0f, st));
+    GCK(rows_pow2(g, w, n_p, m, false, st, r->hhat, 0, vin));    // * filter spectrum in the epilogue
+    GCK(rows_pow2(g, w, n_p, m, true, st, nullptr, 0, vout));
     GCK(scale_copy(w + (r->l_mf - 1) / 2, n_p, n_r, m, r->pc, n_p, n_r, n_r, nullptr, nullptr, 1.0f, st));   // mode='same'
     // 2 window, fftshift . FFT . fftshift over pulses: roll by h = n_p/2 is source row (r - h) mod n
     const int h = n_p / 2, sh = (n_p - h) % n_p;

@@ -46,6 +46,18 @@ def test_rda_oracle(n_r, n_p):
     _check(out, rda.sar_focus_rda(phist, *args))
 
 
+def test_rda_native_range_extent():
+    """13200 range samples with the reference's 12001-tap matched filter: the convolution runs on 32768-point split lines
+    whose zero padding is neither stored nor read."""
+    import sarx
+    from oracle import csa_oracle as orc
+    k = orc.reference_radar_constants()
+    r = np.random.default_rng(12)
+    phist = (r.standard_normal((13200, 24)) + 1j * r.standard_normal((13200, 24))).astype(np.complex64)
+    args = (k["Lambda"], k["T_p"], k["Kr"], k["FS"], k["PRF"], k["V_eff"], k["R0"])
+    _check(sarx.sar_focus_rda(phist, *args), rda.sar_focus_rda(phist, *args))
+
+
 def test_rda_view_input_and_no_intermediates():
     """raw.T (a view) as the scripts pass it; intermediates=False returns None for the three maps."""
     import sarx
