@@ -12,7 +12,9 @@ enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_S
                   AZ_EPI_PROCOL = 5,     // inputs * W_M^(col*m_in) first, outputs * scale (its inverse)
                   AZ_EPI_ROWVEC = 6,     // * rowvec[output row] (Bluestein filter spectrum fused into the forward transform)
                   AZ_EPI_TWIDDLE_PADIN = 7,   // inputs from a smaller [io_rows x io_cols] array (ld io_ld), zero outside, * rowvec[input row]; then TWIDDLE
-                  AZ_EPI_CROPOUT = 8 };       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
+                  AZ_EPI_CROPOUT = 8,
+                  AZ_EPI_TWIDDLE_ROWSIN = 9,  // TWIDDLE, but input rows >= io_rows are zeros that are not read (chirp-z padding)
+                  AZ_EPI_SCALE_ROWSOUT = 10 };  // SCALE, but output rows >= io_rows are not written (only the cropped part is used)       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
 
 struct RangeArgs {
     const float2* in;

@@ -215,6 +215,8 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                     x = a.in[rowi * a.io_ld + col];
                     if (a.rowvec) x = cmul(x, a.rowvec[rowi]);
                 }
+            } else if constexpr (EPI == AZ_EPI_TWIDDLE_ROWSIN) {
+                x = rowi < (size_t)a.io_rows ? a.in[rowi * a.n_rg + col] : make_float2(0.f, 0.f);
             } else if constexpr (EPI == AZ_EPI_TWCOL) {   // zero-padded line: the padding is not stored, let alone read
                 x = (a.valid_len && mi * a.n_rg + col >= a.valid_len) ? make_float2(0.f, 0.f) : a.in[rowi * a.n_rg + col];
             } else {
@@ -235,7 +237,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             const int m = E::out_index(t, b, r);
             const size_t rowo = out_base + (size_t)m * a.out_m_stride;
             cf x = v[b * RL + r];
-            if constexpr (EPI == AZ_EPI_TWIDDLE || EPI == AZ_EPI_TWIDDLE_PADIN) {
+            if constexpr (EPI == AZ_EPI_TWIDDLE || EPI == AZ_EPI_TWIDDLE_PADIN || EPI == AZ_EPI_TWIDDLE_ROWSIN) {
                 // four-step twiddle W_n^(q*m): q*m < n_az <= 2^14 and 1/n_az is a power of two, so the
                 // argument is exact in fp32 (HW sine/cosine take revolutions; no table load in this pass)
 #if SARX_HW_TWIDDLE
@@ -252,6 +254,9 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                 if constexpr (EPI == AZ_EPI_PROCOL) {      // only the cropped part of the line is wanted
                     if (a.valid_len && m * a.n_rg + col >= a.valid_len) continue;
                 }
+                x.x *= a.scale; x.y *= a.scale;
+            } else if constexpr (EPI == AZ_EPI_SCALE_ROWSOUT) {
+                if (rowo >= (size_t)a.io_rows) continue;
                 x.x *= a.scale; x.y *= a.scale;
             } else if constexpr (EPI == AZ_EPI_ROWVEC) {
                 x = cmul(x, a.rowvec[rowo]);
@@ -285,6 +290,7 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_TWCOL: return launch_az_one<R, W, false, AZ_EPI_TWCOL>(a, nq, st);
             case AZ_EPI_ROWVEC: return launch_az_one<R, W, false, AZ_EPI_ROWVEC>(a, nq, st);
             case AZ_EPI_TWIDDLE_PADIN: return launch_az_one<R, W, false, AZ_EPI_TWIDDLE_PADIN>(a, nq, st);
+            case AZ_EPI_TWIDDLE_ROWSIN: return launch_az_one<R, W, false, AZ_EPI_TWIDDLE_ROWSIN>(a, nq, st);
         }
     } else {
         switch (epi) {
@@ -293,6 +299,7 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_SCALE: return launch_az_one<R, W, true, AZ_EPI_SCALE>(a, nq, st);
             case AZ_EPI_PROCOL: return launch_az_one<R, W, true, AZ_EPI_PROCOL>(a, nq, st);
             case AZ_EPI_CROPOUT: return launch_az_one<R, W, true, AZ_EPI_CROPOUT>(a, nq, st);
+            case AZ_EPI_SCALE_ROWSOUT: return launch_az_one<R, W, true, AZ_EPI_SCALE_ROWSOUT>(a, nq, st);
         }
     }
     return hipErrorInvalidValue;

@@ -180,7 +180,8 @@ struct ColsDst { cf* p; size_t ld; int rows, cols; const cf* rowvec; float scale
 static bool cols_two_step(int n) { return n > 128; }
 
 static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n, int ld, bool inv, hipStream_t st,
-                            const cf* rowvec = nullptr, const ColsSrc* src = nullptr, const ColsDst* dst = nullptr) {
+                            const cf* rowvec = nullptr, const ColsSrc* src = nullptr, const ColsDst* dst = nullptr,
+                            int rows_valid = 0) {       // forward: input rows beyond are zeros, not read; inverse: output rows beyond not written
     int l2 = 0;
     while ((1 << l2) < n) ++l2;
     const int S = (n <= 128) ? n : (1 << (l2 / 2)), RA = n / S;
@@ -198,6 +199,7 @@ static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n
     a.in = in; a.out = tmp; a.tw_r = g->tw_all + RA;
     a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
     int epi_first = AZ_EPI_TWIDDLE;
+    if (!src && !inv && rows_valid > 0 && rows_valid < n) { epi_first = AZ_EPI_TWIDDLE_ROWSIN; a.io_rows = rows_valid; }
     if (src) {
         if (inv) return hipErrorInvalidValue;
         epi_first = AZ_EPI_TWIDDLE_PADIN;
@@ -212,6 +214,10 @@ static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n
         a.out = dst->p; a.io_ld = dst->ld; a.io_rows = dst->rows; a.io_cols = dst->cols; a.rowvec = dst->rowvec;
         a.scale = dst->scale / (float)n;
         return launch_az_tile(S, 32, true, AZ_EPI_CROPOUT, a, RA, st);
+    }
+    if (!dst && inv && rows_valid > 0 && rows_valid < n) {
+        a.io_rows = rows_valid;
+        return launch_az_tile(S, 32, true, AZ_EPI_SCALE_ROWSOUT, a, RA, st);
     }
     return launch_az_tile(S, 32, inv, epi_last, a, RA, st);
 }
@@ -318,8 +324,9 @@ static hipError_t cols_core(GeneralCsa* g, cf* x, cf* y, bool inv, hipStream_t s
     const Axis& ax = g->az;
     if (ax.direct) { *res = dst ? nullptr : y; return cols_pow2(g, x, x, y, g->n_az, g->ldc, inv, st, nullptr, src, dst); }
     *res = dst ? nullptr : x;
-    GCK(cols_pow2(g, x, x, y, ax.m, g->ldc, false, st, inv ? ax.bhat_i : ax.bhat_f, src));     // * filter spectrum in the epilogue
-    return cols_pow2(g, y, y, x, ax.m, g->ldc, true, st, nullptr, nullptr, dst);
+    // rows n_az .. m of the padded sequence are zeros on the way in (never read) and unused on the way out (never written)
+    GCK(cols_pow2(g, x, x, y, ax.m, g->ldc, false, st, inv ? ax.bhat_i : ax.bhat_f, src, nullptr, g->n_az));
+    return cols_pow2(g, y, y, x, ax.m, g->ldc, true, st, nullptr, nullptr, dst, g->n_az);
 }
 // line transform in place on w [n_az x m_rg] (chirped and padded when the axis is not direct)
 static hipError_t rows_core(GeneralCsa* g, cf* w, bool inv, hipStream_t st) {
@@ -389,7 +396,7 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
         GCK(rows_pow2(g, lines, n_az, rg.m, false, st, g->ktab, n_az, vlen));
         GCK(rows_pow2(g, lines, n_az, rg.m, true, st, nullptr, 0, vlen));
         // * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a holds the lines)
-        GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, nullptr, 1.0f, st));
+        GCK(bridge<3>(g, lines, lines_ld, wb, ld, fused_ends ? n_az : az.m, ld, az.direct ? nullptr : az.chirp_i, nullptr, 1.0f, st));
     } else {
         // * azimuth post-chirp * Phi_1 (:272-274) * range pre-chirp, into the line array
         GCK(bridge<1>(g, res, ld, lines, lines_ld, n_az, lines_cols, az.direct ? nullptr : az.chirp_f, rg.direct ? nullptr : rg.chirp_f,
@@ -399,8 +406,8 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
         GCK(bridge<2>(g, lines, lines_ld, lines, lines_ld, n_az, lines_cols, nullptr, nullptr, 1.0f, st));
         GCK(rows_core(g, lines, true, st));                                               // :331
         // * range post-chirp / n_rg * Phi_3 (:359-382) * azimuth pre-chirp, into wb (work_a may hold the lines)
-        GCK(bridge<3>(g, lines, lines_ld, wb, ld, az.m, ld, az.direct ? nullptr : az.chirp_i, rg.direct ? nullptr : rg.chirp_i,
-                      rg.direct ? 1.0f : 1.0f / (float)n_rg, st));
+        GCK(bridge<3>(g, lines, lines_ld, wb, ld, fused_ends ? n_az : az.m, ld, az.direct ? nullptr : az.chirp_i,
+                      rg.direct ? nullptr : rg.chirp_i, rg.direct ? 1.0f : 1.0f / (float)n_rg, st));
     }
     if (fused_ends) {                                                                 // :385, post-chirp / n_az and crop in the last launch
         const ColsDst dst{d_out, (size_t)n_rg, n_az, n_rg, az.direct ? nullptr : az.chirp_i, az.direct ? 1.0f : 1.0f / (float)n_az};
