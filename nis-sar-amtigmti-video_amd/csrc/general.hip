@@ -257,9 +257,11 @@ static hipError_t fft_cols(GeneralCsa* g, const cf* src, cf* dst, bool inv, hipS
         return scale_copy(wb, n, C, ld, dst, n, C, C, nullptr, nullptr, 1.0f, st, out_shift, nullptr);
     }
     const cf* chirp = inv ? ax.chirp_i : ax.chirp_f;
-    GCK(scale_copy(src, n, C, C, wa, m, ld, ld, chirp, nullptr, 1.0f, st, in_shift, pre));
-    GCK(cols_pow2(g, wa, wa, wb, m, ld, false, st, inv ? ax.bhat_i : ax.bhat_f));   // filter spectrum in the epilogue; result in wb
-    GCK(cols_pow2(g, wb, wb, wa, m, ld, true, st));                                   // result in wa
+    // rows n .. m of the padded sequence: zeros that are neither written nor read (two-step transforms), unused on the way out
+    const int rv = cols_two_step(m) ? n : 0;
+    GCK(scale_copy(src, n, C, C, wa, rv ? n : m, ld, ld, chirp, nullptr, 1.0f, st, in_shift, pre));
+    GCK(cols_pow2(g, wa, wa, wb, m, ld, false, st, inv ? ax.bhat_i : ax.bhat_f, nullptr, nullptr, rv));   // filter spectrum in the epilogue
+    GCK(cols_pow2(g, wb, wb, wa, m, ld, true, st, nullptr, nullptr, nullptr, rv));                          // result in wa
     // the chirp belongs to the sequence index, i.e. to the source row of this copy
     return scale_copy(wa, n, C, ld, dst, n, C, C, nullptr, nullptr, inv ? 1.0f / (float)n : 1.0f, st, out_shift, chirp);
 }
