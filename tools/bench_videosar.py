@@ -46,3 +46,12 @@ for rep in range(2):
     out = sarx.sar_focus_rda(raw.T, *args, intermediates=False)
     t1 = time.perf_counter()
 print(f"sar_focus_rda {n_r} x {n_az} host in / magnitude out: {1e3 * (t1 - t0):.1f} ms wall")
+
+# the same with the pulses already on the GPU (as the echo kernels leave them): focus + magnitude download only
+d = sarx.DeviceArray(ctx.to_device(raw), raw.shape)
+for rep in range(2):
+    t0 = time.perf_counter()
+    out = sarx.sar_focus_rda(d.T, *args, intermediates=False)
+    t1 = time.perf_counter()
+d.release()
+print(f"sar_focus_rda {n_r} x {n_az} device in / magnitude out: {1e3 * (t1 - t0):.1f} ms wall")
