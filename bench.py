@@ -225,6 +225,11 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launch_ms": rg_ms / launches, "algorithmic_bytes_per_launch": 16.0 * n * n},
         }
+        if not a.unfused:
+            # SURVEY.md 8(d) counts 16 B/sample per FFT(+phase) pass; this launch does two of them (FFT+Phi2, IFFT+Phi3)
+            # on one HBM round trip.  `achieved` counts the bytes it really moves (16 B/sample); by pass accounting:
+            line["roofline"]["survey_passes_in_launch"] = 2
+            line["roofline"]["achieved_by_pass_accounting"] = 2 * achieved
         if per_pass:
             # the standalone range FFT + Phi_2 launch BASELINE.json's 70 % target names, and the others
             p2 = per_pass["rg_fft_phi2"]
