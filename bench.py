@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """bench.py - focused SAR frames/sec + HBM GB/s of the range FFT+phase pass.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384] [--stack multilook|magnitude]
 
-One step = one CSA focus (azimuth FFT+Phi1, range FFT+Phi2+IFFT+Phi3, azimuth
-IFFT) of one 16384x16384 complex64 frame whose echo is already resident in HBM
-(synthetic complex Gaussian noise generated on the device).  For N > 1 the
-driver starts one process per GPU (torch.distributed.run); frames shard
-one-per-rank per step (weak scaling) and each step's frame is multilooked
-16x16 into its VideoSAR stack slot and all-gathered with RCCL on a second
-stream.  torch is used only for the gloo rendezvous/barrier; the GPU path is
-libsarx through ctypes.
+One step = one CSA focus (azimuth FFT+Phi1, range FFT+Phi2+IFFT+Phi3, azimuth IFFT) of one 16384x16384 complex64
+frame whose echo is already resident in HBM (synthetic complex Gaussian noise generated on the device): BASELINE.json
+config 4, the configuration the metric is quoted on.
+
+--gpus N > 1: one process per GPU.  Started bare (`python bench.py --gpus N`, WORLD_SIZE unset) this file spawns the N
+ranks itself as fresh child processes (`python -m torch.distributed.run ... bench.py ...`) BEFORE anything touches the
+GPU, relays rank 0's JSON line and exits with the children's code; started under torch.distributed.run it is one of
+the ranks (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  `--gpus` disagreeing with WORLD_SIZE is an error,
+never a silent 1-GPU run.  At N > 1 frames shard one per rank per step (weak scaling) and each step's frame is
+multilooked 16x16 into its VideoSAR stack slot and all-gathered with RCCL on a second stream.
+
+Every line also carries a `batch64` block: BASELINE.json config 5, the 64-frame VideoSAR batch of two-channel 8192^2
+scenes, frame f -> rank f mod N, strong scaling (sarx.batch.TwoChannelBatch, the driver the tests run too).
+
+torch is used only for the gloo rendezvous/barrier; the GPU path is libsarx through ctypes.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,40 +36,109 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s mea
 LOOKS = 16
 
 
-def cpu_baseline(size, workers=1):
-    """Oracle ("port") timed on this box's host cores on a bounded sample: single thread (what the reference's
-    NumPy code uses) by default; workers > 1 = the same arithmetic with threaded FFTs and row blocks in a pool."""
-    import numpy as np
-    from oracle import csa_oracle as orc
-    n = min(size, 8192)                      # ~10-20 s of single-thread CPU work
-    k = orc.scaled_radar(n, n)
-    rng = np.random.default_rng(0)
-    raw = (rng.standard_normal((n, n), dtype=np.float32) + 1j * rng.standard_normal((n, n), dtype=np.float32))
-    raw = raw.astype(np.complex64)
-    best = 1e30
-    for _ in range(1):
-        t = time.perf_counter()
-        orc.sar_focus_csa_lean(raw, *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)
-        best = min(best, time.perf_counter() - t)
-    scale = (size / n) ** 2                      # samples per full frame / samples in the sample
-    return {"value": 1.0 / (best * scale), "unit": "frames/s", "cores": workers, "kind": "port",
-            "sample": f"{n}x{n} complex64 noise frame, oracle/csa_oracle.sar_focus_csa_lean (NumPy/scipy.fft, "
-                      f"{workers} thread(s) of {os.cpu_count()}), {best:.2f} s, scaled x{scale:.0f} by sample count to "
-                      f"{size}x{size}"}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE or 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--unfused", action="store_true", help="run range passes 2 and 3 as two launches")
-    ap.add_argument("--passes", action="store_true", help="also time every pass alone (stderr)")
+    ap.add_argument("--passes", action="store_true", help="also print every pass alone to stderr")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    a = ap.parse_args()
+    ap.add_argument("--no-batch", action="store_true", help="skip the batch64 block (BASELINE config 5)")
+    ap.add_argument("--batch-frames", type=int, default=64)
+    ap.add_argument("--batch-size", type=int, default=8192)
+    ap.add_argument("--stack", choices=("multilook", "magnitude", "both"), default="multilook",
+                    help="batch64 stack slot: 16x16 multilook (1 MiB/frame at 8192^2; headline), full-resolution "
+                         "magnitude (256 MiB/frame: loads xGMI), or both one after the other")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only: every rank reports (rank, local rank, world) and exits before touching the GPU")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def spawn_ranks(n, argv):
+    """Start n ranks as fresh child processes (this process has not touched the GPU and never will)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL across processes needs dmabuf IPC on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"[bench] spawning {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_baseline(size, workers=1, scaled=True):
+    """Oracle ("port") timed on this box's host cores.  scaled: an 8192^2 sample on one thread (how the reference's
+    NumPy runs), scaled x4 by sample count; not scaled: the real size x size frame, row-blocked, `workers` threads."""
+    import numpy as np
+    from oracle import csa_oracle as orc
+    n = min(size, 8192) if scaled else size
+    k = orc.scaled_radar(n, n)
+    rng = np.random.default_rng(0)
+    raw = np.empty((n, n), dtype=np.complex64)
+    for i0 in range(0, n, 1024):                                     # in pieces: no n x n float64 temporaries
+        blk = rng.standard_normal((min(1024, n - i0), n, 2), dtype=np.float32)
+        raw[i0:i0 + blk.shape[0]] = blk[..., 0] + 1j * blk[..., 1]
+    t = time.perf_counter()
+    orc.sar_focus_csa_lean(raw, *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)
+    best = time.perf_counter() - t
+    scale = (size / n) ** 2                      # samples per full frame / samples in the sample
+    how = (f"scaled x{scale:.0f} by sample count to {size}x{size}" if scale != 1 else "the full frame, not scaled")
+    return {"value": 1.0 / (best * scale), "unit": "frames/s", "cores": workers, "kind": "port",
+            "sample": f"{n}x{n} complex64 noise frame, oracle/csa_oracle.sar_focus_csa_lean (NumPy/scipy.fft, "
+                      f"{workers} thread(s) of {os.cpu_count()}), {best:.2f} s, {how}"}
+
+
+def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, stack):
+    """BASELINE config 5 through the shared device driver; returns the block for the JSON line (rank 0) or None."""
+    from sarx.batch import TwoChannelBatch
+    b = TwoChannelBatch(ctx, a.batch_size, a.batch_frames, world, rank, stack=stack, looks=LOOKS, rccl=use_rccl and world > 1,
+                        host_comm=None if (use_rccl or world == 1) else host_comm)
+    b.run()                                                      # warm-up batch
+    barrier()
+    t0 = time.perf_counter()
+    b.run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    import numpy as np
+    probe = b.stack(frames=[0, a.batch_frames - 1])
+    assert np.isfinite(probe).all() and probe.min() >= 0 and probe.max() > 0, "stack slot not finite / empty"
+    slot_bytes = b.slot_bytes
+    b.close()
+    if rank != 0:
+        return None
+    return {"metric": "VideoSAR batch frames/sec (two-channel CSA focus + ATI/DPCA + mask, stack all-gather)",
+            "value": a.batch_frames / dt, "unit": "frames/s", "batch_s": dt, "scaling": "strong", "n_gpus": world,
+            "workload": f"{a.batch_frames} frames x two-channel {a.batch_size}x{a.batch_size} complex64 (BASELINE config 5), "
+                        f"frame f -> rank f mod {world}, echoes device-resident",
+            "stack": (f"{LOOKS}x{LOOKS} multilook of |slc1|^2" if stack == "multilook" else "full-resolution |slc1|") +
+                     f", {slot_bytes / 2**20:.0f} MiB per frame, gathered in place once per round of {world} frame(s)",
+            "gather_bytes_per_rank_per_round": slot_bytes}
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if a.gpus is not None and a.gpus > 1:                    # bare `python bench.py --gpus N`: become the launcher
+            sys.exit(spawn_ranks(a.gpus, argv))
+        world = 1
+    else:
+        world = int(env_world)
+        if a.gpus is not None and a.gpus != world:
+            print(f"[bench] --gpus {a.gpus} disagrees with WORLD_SIZE={world}; refusing to report a wrong n_gpus",
+                  file=sys.stderr, flush=True)
+            sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -69,11 +147,25 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if a.dry_run:                                                # launcher / rendezvous check, no GPU needed
+        me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid()}
+        ranks = [me]
+        if dist is not None:
+            ranks = [None] * world
+            dist.all_gather_object(ranks, me)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks}), flush=True)
+        return
+
+    import numpy as np
     import sarx
     from sarx import _ffi, radar
+    from sarx.batch import TorchStackComm, agree_on_rccl
 
     n_dev = max(1, sarx.device_count())
-    ctx = sarx.Context(local_rank % n_dev)              # one rank per GPU; wraps only when ranks outnumber GPUs (tests)
+    ctx = sarx.Context(local_rank % n_dev)              # one rank per GPU; wraps only when ranks outnumber GPUs (rehearsals)
     n = a.size
     K, W = a.steps, a.warmup
     flags = 0 if a.unfused else _ffi.FUSE_RANGE
@@ -81,55 +173,24 @@ def main():
     d_in, d_img = ctx.alloc(n * n * 8), ctx.alloc(n * n * 8)
     ctx.fill_noise(d_in, n * n, 1000 + rank)
 
-    comm = host_comm = d_slot = d_recv = None
-    collective = None
+    # ---- collective: RCCL over xGMI; gloo through host memory only if RCCL cannot come up on every rank -------------
+    use_rccl, host_comm, collective, rccl = False, None, None, None
     slot_bytes = (n // LOOKS) * (n // LOOKS) * 4
     force_comm = os.environ.get("SARX_BENCH_FORCE_COMM") == "1"     # exercise the gather path on one GPU
+    d_recv = None
     if world > 1 or force_comm:
-        def bootstrap(uid):
-            if dist is None:
-                return uid
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        # RCCL over xGMI is the collective.  If its bootstrap fails on every rank alike (it needs dmabuf IPC,
-        # HSA_ENABLE_IPC_MODE_LEGACY=0), the stack slots travel through the gloo group instead - slower, said so in
-        # the JSON line - rather than losing the whole scaling run.
-        uid, ok = None, 1
-        if rank == 0:
-            try:
-                uid = ctx.comm_unique_id()
-            except Exception as exc:                          # noqa: BLE001
-                print(f"[bench rank 0] RCCL unique id failed: {exc}", file=sys.stderr, flush=True)
-        uid = bootstrap(uid)                                  # every rank takes part, also after a failure on rank 0
-        if uid is None:
-            ok = 0
+        log = lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)
+        use_rccl = agree_on_rccl(ctx, world, rank, dist, log)
+        try:
+            rccl = sarx.Context.rccl_info()
+        except sarx.SarxError as exc:
+            rccl = {"error": str(exc)}
+        if use_rccl:
+            collective = "RCCL all-gather (in place) on the comm stream"
         else:
-            try:
-                ctx.comm_init(uid, world, rank)
-                comm = True
-            except Exception as exc:                          # noqa: BLE001
-                ok = 0
-                print(f"[bench rank {rank}] RCCL init failed: {exc}", file=sys.stderr, flush=True)
-        if dist is not None:
-            import torch
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        if ok:
-            collective = "RCCL all-gather of the stack slot"
-            d_slot = ctx.alloc(slot_bytes * 2)                # double-buffered send slots
-            d_recv = ctx.alloc(slot_bytes * world * 2)        # double-buffered round blocks
-        else:
-            if comm is not None:
-                ctx.lib.sarx_comm_destroy(ctx.h)
-            comm = None
-            from sarx.batch import TorchStackComm
             host_comm = TorchStackComm() if dist is not None else None
-            collective = "gloo all-gather of the stack slot through host memory (RCCL init failed)"
-            d_slot = ctx.alloc(slot_bytes * 2)
-
-    import numpy as np
+            collective = "gloo all-gather through host memory (RCCL did not come up on every rank: see stderr)"
+        d_recv = ctx.alloc(slot_bytes * world * 2)                # two round blocks, alternating
 
     def step(s, mark):
         if mark and 2 * s + 1 < 256:
@@ -137,14 +198,20 @@ def main():
         else:
             plan.mark_range(-1, -1)
         plan.focus_dev(d_in, d_img)
-        if comm is not None:
-            ctx.comm_fence_compute()                      # slot (s&1) was last read by the gather of step s-2
-            ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, d_slot.ptr + (s & 1) * slot_bytes, n, n, LOOKS)
-            ctx.lib.sarx_allgather_dev(ctx.h, d_slot.ptr + (s & 1) * slot_bytes,
-                                       d_recv.ptr + (s & 1) * slot_bytes * world, slot_bytes)
-        elif host_comm is not None:
-            ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, d_slot.ptr, n, n, LOOKS)
-            host_comm.all_gather(d_slot.download(np.float32, (n // LOOKS, n // LOOKS)))
+        if d_recv is None:
+            return
+        block = d_recv.ptr + (s & 1) * slot_bytes * world
+        mine = block + rank * slot_bytes
+        if use_rccl:
+            ctx.comm_fence_compute()                      # block (s&1) was last read/written by the gather of step s-2
+            ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, mine, n, n, LOOKS)
+            ctx.lib.sarx_allgather_dev(ctx.h, mine, block, slot_bytes)
+        else:
+            ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, mine, n, n, LOOKS)
+            if host_comm is not None:
+                slot = np.empty((n // LOOKS, n // LOOKS), dtype=np.float32)
+                _ffi.check(ctx.lib.sarx_memcpy_d2h(ctx.h, slot.ctypes.data, mine, slot_bytes), ctx.h)
+                host_comm.all_gather(slot)
 
     def barrier():
         ctx.sync()
@@ -172,7 +239,6 @@ def main():
     alg_bytes = 16.0 * n * n * launches            # one c64 read + one c64 write per sample per launch
     achieved = alg_bytes / (rg_ms * 1e-3) / 1e9
 
-    import numpy as np
     probe = d_img.download(np.complex64, (4, n))
     assert np.isfinite(probe).all() and np.abs(probe).max() > 0, "focused image is not finite / all zero"
 
@@ -198,16 +264,21 @@ def main():
                       f"{16.0 * n * n * launches_ / ms / 1e6:8.1f} GB/s per launch at 16 B/sample", file=sys.stderr)
         tmp.release()
 
-    # HBM bytes per launch from PMC counters (collected in separate rocprofv3 --pmc runs, see the file)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
-        if n == 16384 and not a.unfused:
-            traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "range_fused_wl" in k)
-    except (OSError, StopIteration, KeyError, ValueError):
-        traffic = None
+    # HBM bytes per launch: PMC counters cannot be read inside this process; the figure is REPLAYED from the separate
+    # rocprofv3 --pmc passes kept under profiles/ (tools/pmc_traffic.sh), and labelled as such
+    traffic, traffic_src = None, None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                pmc = json.load(fh)
+            if n == 16384 and not a.unfused:
+                traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "range_fused" in k)
+                traffic_src = f"replayed from profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), not measured in this run"
+                break
+        except (OSError, StopIteration, KeyError, ValueError):
+            continue
 
+    line = None
     if rank == 0:
         line = {
             "metric": "focused SAR frames/sec (CSA focus, complex64)", "value": world * K / dt, "unit": "frames/s",
@@ -223,13 +294,15 @@ def main():
                                                     "range_pass_kernel<fused>" if not a.unfused else
                                                     "range_pass_v2_kernel<FFT+Phi2>, <IFFT+Phi3>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "launch_ms": rg_ms / launches, "algorithmic_bytes_per_launch": 16.0 * n * n},
+                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": rg_ms / launches,
+                         "algorithmic_bytes_per_launch": 16.0 * n * n},
         }
+        if collective:
+            line["collective"] = {"transport": collective, "ranks": world, "rccl": rccl}
         if not a.unfused:
             # SURVEY.md 8(d) counts 16 B/sample per FFT(+phase) pass; this launch does two of them (FFT+Phi2, IFFT+Phi3)
-            # on one HBM round trip.  `achieved` counts the bytes it really moves (16 B/sample); by pass accounting:
+            # on one HBM round trip.  `achieved` counts the bytes it really moves (16 B/sample), once.
             line["roofline"]["survey_passes_in_launch"] = 2
-            line["roofline"]["achieved_by_pass_accounting"] = 2 * achieved
         if per_pass:
             # the standalone range FFT + Phi_2 launch BASELINE.json's 70 % target names, and the others
             p2 = per_pass["rg_fft_phi2"]
@@ -238,11 +311,28 @@ def main():
                 "frac": p2["GBps_per_launch"] / HBM_PEAK_GBS, "launch_ms": p2["ms"],
                 "note": "same launch outside the timed region; the default path runs it fused with pass 3"}
             line["passes"] = per_pass
+
+    # the config-4 buffers make room for config 5
+    plan.close()
+    d_in.release()
+    d_img.release()
+    if d_recv is not None:
+        d_recv.release()
+
+    if not a.no_batch:
+        stacks = ("multilook", "magnitude") if a.stack == "both" else (a.stack,)
+        for st in stacks:
+            blk = run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, st)
+            if rank == 0:
+                blk["collective"] = collective or "none (one rank)"
+                line["batch64" if st == "multilook" else "batch64_magnitude"] = blk
+
+    if rank == 0:
         if world == 1 and not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(n)
             mt = min(os.cpu_count() or 1, 32)
-            if mt > 1:                              # the fair all-core figure next to the reference-style single thread
-                line["cpu_baseline_threads"] = cpu_baseline(n, workers=mt)
+            if mt > 1:                              # the all-core figure on the real frame next to the reference-style single thread
+                line["cpu_baseline_threads"] = cpu_baseline(n, workers=mt, scaled=False)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

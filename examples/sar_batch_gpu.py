@@ -83,7 +83,8 @@ def main():
                 return img.astype(np.complex64).view(np.float32)                               # stack slot [ny x 2 nx]
 
             comm = TorchStackComm() if world > 1 else LocalStackComm()
-            stack = np.ascontiguousarray(run_batch_host(frame_ids, world, rank, process_frame, comm)).view(np.complex64)
+            stack = np.ascontiguousarray(run_batch_host(frame_ids, world, rank, process_frame, comm,
+                                                              slot_shape=(a.nx, 2 * a.nx))).view(np.complex64)
             if state["d_raw"] is not None:
                 state["d_raw"].release()
             ctx.sync()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 100
+#define SARX_VERSION 200
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -80,6 +80,9 @@ int sarx_version(void);
 int sarx_device_count(int* out_count);
 int sarx_device_info(sarx_ctx* ctx, char* name, size_t name_len, int* compute_units,
                      uint64_t* hbm_bytes, char* arch, size_t arch_len);
+/* grid size the persistent range kernels use: min(wgs_per_cu * cus, work_items), at least 1; cus is the compute-unit
+ * count of the ctx's own device (pure host arithmetic, no device needed) */
+int sarx_persistent_grid(int wgs_per_cu, int cus, int work_items);
 
 /* ---- device memory and timing (so the Python host needs no torch) -------- */
 int sarx_malloc(sarx_ctx* ctx, size_t bytes, void** out_dptr);
@@ -87,6 +90,11 @@ int sarx_free(sarx_ctx* ctx, void* dptr);
 int sarx_memcpy_h2d(sarx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int sarx_memcpy_d2h(sarx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int sarx_memcpy_d2d(sarx_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+/* strided copies (rows of `width` bytes, pitches in bytes), blocking: sample columns / blocks of a device image */
+int sarx_memcpy2d_d2h(sarx_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+                      size_t width, size_t height);
+int sarx_memcpy2d_h2d(sarx_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch,
+                      size_t width, size_t height);
 int sarx_memset(sarx_ctx* ctx, void* dst_dev, int value, size_t bytes);
 int sarx_sync(sarx_ctx* ctx);
 /* HIP events on the ctx stream: record `slot` (0..255); elapsed ms between two recorded slots */
@@ -158,6 +166,15 @@ typedef struct {
  * viewer :249).  Results land in host doubles after an internal sync. */
 int sarx_ati_dpca_dev(sarx_ctx* ctx, const void* d_slc1, const void* d_slc2, size_t n, double cal_phase,
                       const sarx_ati_outputs* d_out, double* max_mag, double* sum_interf_re_im /*[2]*/);
+/* All ATI/DPCA buffers must be 16-byte aligned.  With max_mag and sum_interf_re_im both NULL the call only enqueues;
+ * sarx_ati_stats fetches the two reductions of the most recent launch on this ctx later (blocking). */
+int sarx_ati_stats(sarx_ctx* ctx, double* max_mag, double* sum_interf_re_im /*[2]*/);
+/* ati_phase[~(mag > mask_frac * max|slc1|)] = 0 with the maximum taken on the device from the most recent
+ * sarx_ati_dpca_dev launch of this ctx (sar_ati_dcpa_sim_csa.py:447-449 without a host round trip) */
+int sarx_mask_phase_frac_dev(sarx_ctx* ctx, const float* d_phase, const float* d_mag, size_t n, float mask_frac,
+                             float* d_out);
+/* out[i] = |in[i]|, complex64 in, fp32 out (sar_ati_dcpa_sim_csa.py:416 on its own: full-resolution stack slot) */
+int sarx_magnitude_dev(sarx_ctx* ctx, const void* d_in, float* d_out, size_t n);
 /* ati_phase[~(mag > thr)] = 0  (sar_ati_dcpa_sim_csa.py:447-449); d_out may alias d_phase */
 int sarx_mask_phase_dev(sarx_ctx* ctx, const float* d_phase, const float* d_mag, size_t n, float threshold,
                         float* d_out);
@@ -244,6 +261,10 @@ int sarx_tdbp_last_window(const sarx_tdbp_plan* plan, int* lo, int* hi);
 /* ---- multi-GPU: RCCL all-gather of the image stack over xGMI ------------- */
 #define SARX_COMM_ID_BYTES 128
 int sarx_comm_unique_id(void* id_out /*[SARX_COMM_ID_BYTES]*/);
+/* which RCCL the collectives run on: file path, ncclGetVersion of it, NCCL_VERSION_CODE of the headers libsarx was
+ * compiled against.  libsarx takes librccl from the directory of the HIP runtime the process is running on (a process
+ * that imported torch first runs on torch's bundled runtime and RCCL), SARX_RCCL_PATH overrides. */
+int sarx_rccl_info(char* path, size_t path_len, int* version, int* header_version);
 int sarx_comm_init(sarx_ctx* ctx, const void* id, int n_ranks, int rank);
 /* recv[rank r] = send of rank r; bytes_per_rank multiple of 4; async on the ctx comm stream,
  * ordered after everything already enqueued on the compute stream */

@@ -50,13 +50,24 @@ struct AzArgs {
     int in_q_stride, in_m_stride, out_q_stride, out_m_stride;
 };
 
+// Grid of a persistent kernel: wgs_per_cu resident workgroups on each of `cus` compute units, never more workgroups
+// than work items, at least one.  cus comes from the ctx of the device being launched on (never a process-wide cache).
+inline int persistent_grid(int wgs_per_cu, int cus, int work_items) {
+    if (wgs_per_cu < 1) wgs_per_cu = 1;
+    if (cus < 1) cus = 1;
+    long long g = (long long)wgs_per_cu * cus;
+    if (g > work_items) g = work_items;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 hipError_t launch_range_pass(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
 // range_v2.hip: 32 points/thread, split re/im exchange (two lines resident per CU at 16384)
 bool range_v2_supported(int n_rg);
-hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
+hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st);
 // range_fused_wl.hip: fused FFT.Phi2.IFFT.Phi3 at 16384 with wave-private sub-transforms
 bool range_fused_wl_supported(int n_rg);
-hipError_t launch_range_fused_wl(const RangeArgs& a, hipStream_t st);
+hipError_t launch_range_fused_wl(const RangeArgs& a, int cus, hipStream_t st);
 // r: FFT length of the tile (2..128), w: tile width in range samples (16 or 32), nq: tiles along azimuth
 hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int nq, hipStream_t st);
 
@@ -82,6 +93,10 @@ int ati_blocks(size_t n);
 hipError_t launch_ati_dpca(const AtiArgs& a, hipStream_t st);
 hipError_t launch_ati_finish(const float* part_max, const double2* part_sum, int blocks, double* out3, hipStream_t st);
 hipError_t launch_mask_phase(const float* phase, const float* mag, size_t n, float thr, float* out, hipStream_t st);
+// thr = frac * out3[0] on the device (out3 = {max|slc1|, sum re, sum im} of the last ATI launch)
+hipError_t launch_mask_phase_frac(const float* phase, const float* mag, size_t n, float frac, const double* out3, float* out,
+                                  hipStream_t st);
+hipError_t launch_magnitude(const float2* in, float* out, size_t n, hipStream_t st);
 hipError_t launch_corner_turn(const float2* in, float2* out, int rows, int cols, hipStream_t st);
 hipError_t launch_multilook(const float2* in, float* out, int rows, int cols, int looks, hipStream_t st);
 hipError_t launch_fill_noise(float2* buf, size_t n, uint64_t seed, hipStream_t st);

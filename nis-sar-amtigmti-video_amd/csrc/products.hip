@@ -11,8 +11,8 @@ static constexpr int ATI_THREADS = 256;
 static constexpr int ATI_MAX_BLOCKS = 4096;
 
 int ati_blocks(size_t n) {
-    size_t pairs = (n + 1) / 2;
-    size_t b = (pairs + ATI_THREADS - 1) / ATI_THREADS;
+    size_t quads = (n + 3) / 4;
+    size_t b = (quads + ATI_THREADS - 1) / ATI_THREADS;
     if (b > ATI_MAX_BLOCKS) b = ATI_MAX_BLOCKS;
     if (b < 1) b = 1;
     return (int)b;
@@ -44,35 +44,47 @@ template <bool OPT> __device__ __forceinline__ void ati_pixel(cf a, cf b, float 
     }
 }
 
+// Four pixels per lane: two 16-byte loads per channel, one 16-byte store per fp32 plane (28 B/pixel in all).
 template <bool OPT> __global__ __launch_bounds__(ATI_THREADS) void ati_dpca_kernel(AtiArgs a) {
-    const size_t npair = a.n / 2;
+    const size_t nquad = a.n / 4;
     const size_t stride = (size_t)gridDim.x * ATI_THREADS;
     float vmax = 0.f;
     double sre = 0.0, sim = 0.0;
     const float4* s1 = reinterpret_cast<const float4*>(a.s1);
     const float4* s2 = reinterpret_cast<const float4*>(a.s2);
-    for (size_t i = (size_t)blockIdx.x * ATI_THREADS + threadIdx.x; i < npair; i += stride) {
-        const float4 x = s1[i], y = s2[i];
-        Pix p0, p1;
-        ati_pixel<OPT>(make_float2(x.x, x.y), make_float2(y.x, y.y), a.cal_c, a.cal_s, p0);
-        ati_pixel<OPT>(make_float2(x.z, x.w), make_float2(y.z, y.w), a.cal_c, a.cal_s, p1);
-        reinterpret_cast<float2*>(a.ati_phase)[i] = make_float2(p0.phase, p1.phase);
-        reinterpret_cast<float2*>(a.mag1)[i] = make_float2(p0.m1, p1.m1);
-        reinterpret_cast<float2*>(a.dpca_mag)[i] = make_float2(p0.dm, p1.dm);
+    for (size_t i = (size_t)blockIdx.x * ATI_THREADS + threadIdx.x; i < nquad; i += stride) {
+        const float4 x0 = s1[2 * i], x1 = s1[2 * i + 1], y0 = s2[2 * i], y1 = s2[2 * i + 1];
+        Pix p[4];
+        ati_pixel<OPT>(make_float2(x0.x, x0.y), make_float2(y0.x, y0.y), a.cal_c, a.cal_s, p[0]);
+        ati_pixel<OPT>(make_float2(x0.z, x0.w), make_float2(y0.z, y0.w), a.cal_c, a.cal_s, p[1]);
+        ati_pixel<OPT>(make_float2(x1.x, x1.y), make_float2(y1.x, y1.y), a.cal_c, a.cal_s, p[2]);
+        ati_pixel<OPT>(make_float2(x1.z, x1.w), make_float2(y1.z, y1.w), a.cal_c, a.cal_s, p[3]);
+        reinterpret_cast<float4*>(a.ati_phase)[i] = make_float4(p[0].phase, p[1].phase, p[2].phase, p[3].phase);
+        reinterpret_cast<float4*>(a.mag1)[i] = make_float4(p[0].m1, p[1].m1, p[2].m1, p[3].m1);
+        reinterpret_cast<float4*>(a.dpca_mag)[i] = make_float4(p[0].dm, p[1].dm, p[2].dm, p[3].dm);
         if (OPT) {
-            if (a.interf) reinterpret_cast<float4*>(a.interf)[i] = make_float4(p0.interf.x, p0.interf.y, p1.interf.x, p1.interf.y);
-            if (a.diff) reinterpret_cast<float4*>(a.diff)[i] = make_float4(p0.diff.x, p0.diff.y, p1.diff.x, p1.diff.y);
-            if (a.mag2) reinterpret_cast<float2*>(a.mag2)[i] = make_float2(p0.m2, p1.m2);
-            if (a.ph1) reinterpret_cast<float2*>(a.ph1)[i] = make_float2(p0.p1, p1.p1);
-            if (a.ph2) reinterpret_cast<float2*>(a.ph2)[i] = make_float2(p0.p2, p1.p2);
-            if (a.dpca_phase) reinterpret_cast<float2*>(a.dpca_phase)[i] = make_float2(p0.dp, p1.dp);
+            if (a.interf) {
+                reinterpret_cast<float4*>(a.interf)[2 * i] = make_float4(p[0].interf.x, p[0].interf.y, p[1].interf.x, p[1].interf.y);
+                reinterpret_cast<float4*>(a.interf)[2 * i + 1] = make_float4(p[2].interf.x, p[2].interf.y, p[3].interf.x, p[3].interf.y);
+            }
+            if (a.diff) {
+                reinterpret_cast<float4*>(a.diff)[2 * i] = make_float4(p[0].diff.x, p[0].diff.y, p[1].diff.x, p[1].diff.y);
+                reinterpret_cast<float4*>(a.diff)[2 * i + 1] = make_float4(p[2].diff.x, p[2].diff.y, p[3].diff.x, p[3].diff.y);
+            }
+            if (a.mag2) reinterpret_cast<float4*>(a.mag2)[i] = make_float4(p[0].m2, p[1].m2, p[2].m2, p[3].m2);
+            if (a.ph1) reinterpret_cast<float4*>(a.ph1)[i] = make_float4(p[0].p1, p[1].p1, p[2].p1, p[3].p1);
+            if (a.ph2) reinterpret_cast<float4*>(a.ph2)[i] = make_float4(p[0].p2, p[1].p2, p[2].p2, p[3].p2);
+            if (a.dpca_phase) reinterpret_cast<float4*>(a.dpca_phase)[i] = make_float4(p[0].dp, p[1].dp, p[2].dp, p[3].dp);
         }
-        vmax = fmaxf(vmax, fmaxf(p0.m1, p1.m1));
-        sre += p0.sre + p1.sre;
-        sim += p0.sim + p1.sim;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            vmax = fmaxf(vmax, p[k].m1);
+            sre += p[k].sre;
+            sim += p[k].sim;
+        }
     }
-    if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd tail pixel
-        const size_t i = a.n - 1;
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {   // tail pixels
+        const size_t i = nquad * 4 + threadIdx.x;
         Pix p;
         ati_pixel<OPT>(a.s1[i], a.s2[i], a.cal_c, a.cal_s, p);
         a.ati_phase[i] = p.phase; a.mag1[i] = p.m1; a.dpca_mag[i] = p.dm;
@@ -156,11 +168,57 @@ __global__ __launch_bounds__(256) void mask_phase_kernel(const float* phase, con
         out[i] = mag[i] > thr ? phase[i] : 0.f;
     }
 }
+// the same with thr = frac * max|slc1| taken from the ATI launch's device-side result (no host round trip)
+__global__ __launch_bounds__(256) void mask_phase_frac_kernel(const float* phase, const float* mag, size_t n, float frac,
+                                                              const double* out3, float* out) {
+    const float thr = (float)out3[0] * frac;          // float32 product, as the host facade computes it
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 p = reinterpret_cast<const float4*>(phase)[i];
+        const float4 m = reinterpret_cast<const float4*>(mag)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(m.x > thr ? p.x : 0.f, m.y > thr ? p.y : 0.f,
+                                                        m.z > thr ? p.z : 0.f, m.w > thr ? p.w : 0.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        out[i] = mag[i] > thr ? phase[i] : 0.f;
+    }
+}
+hipError_t launch_mask_phase_frac(const float* phase, const float* mag, size_t n, float frac, const double* out3, float* out,
+                                  hipStream_t st) {
+    size_t b = (n / 4 + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(mask_phase_frac_kernel, dim3((unsigned)b), dim3(256), 0, st, phase, mag, n, frac, out3, out);
+    return hipGetLastError();
+}
 hipError_t launch_mask_phase(const float* phase, const float* mag, size_t n, float thr, float* out, hipStream_t st) {
     size_t b = (n / 4 + 255) / 256;
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
     hipLaunchKernelGGL(mask_phase_kernel, dim3((unsigned)b), dim3(256), 0, st, phase, mag, n, thr, out);
+    return hipGetLastError();
+}
+
+// |x| of a complex64 buffer (full-resolution magnitude stack slot), 16 B per lane both ways where n allows
+__global__ __launch_bounds__(256) void magnitude_kernel(const cf* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(in)[2 * i], b = reinterpret_cast<const float4*>(in)[2 * i + 1];
+        reinterpret_cast<float4*>(out)[i] = make_float4(hypotf(a.x, a.y), hypotf(a.z, a.w), hypotf(b.x, b.y), hypotf(b.z, b.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        out[i] = hypotf(in[i].x, in[i].y);
+    }
+}
+hipError_t launch_magnitude(const cf* in, float* out, size_t n, hipStream_t st) {
+    size_t b = (n / 4 + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(magnitude_kernel, dim3((unsigned)b), dim3(256), 0, st, in, out, n);
     return hipGetLastError();
 }
 

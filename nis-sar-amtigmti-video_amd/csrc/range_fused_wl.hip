@@ -169,21 +169,14 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
 
 bool range_fused_wl_supported(int n_rg) { return n_rg == wl::N; }
 
-hipError_t launch_range_fused_wl(const RangeArgs& a, hipStream_t st) {
-    static bool attr_set = false;
-    static int cus = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_fused_wl_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-        attr_set = true;
-    }
-    int grid = cus;                                    // one resident workgroup per CU, persistent over lines
-    if (grid > a.n_az) grid = a.n_az;
+// cus: compute units of the device the stream belongs to (from the ctx).  The 136 KiB dynamic-LDS opt-in is a
+// per-device attribute of the function, so it is set on every launch like the other launchers do (a process may own
+// contexts on several GPUs; a once-per-process flag would leave the second device without it).
+hipError_t launch_range_fused_wl(const RangeArgs& a, int cus, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_fused_wl_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int grid = persistent_grid(1, cus, a.n_az);   // one resident workgroup per CU, persistent over lines
     hipLaunchKernelGGL(range_fused_wl_kernel, dim3(grid), dim3(wl::THREADS), wl::LDS_BYTES, st, a);
     return hipGetLastError();
 }

@@ -17,17 +17,6 @@
 
 namespace sarx {
 
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
 template <int N> struct V2 {
     using PL = Plan<N>;
     static constexpr int P = 32;
@@ -239,7 +228,7 @@ __global__ __launch_bounds__(V2<N>::THREADS, 4) void range_pass_v2_kernel(RangeA
     }
 }
 
-template <int N, int MODE> static hipError_t launch_v2(const RangeArgs& a, hipStream_t st) {
+template <int N, int MODE> static hipError_t launch_v2(const RangeArgs& a, int cus, hipStream_t st) {
     using CFG = V2<N>;
     auto k = range_pass_v2_kernel<N, MODE>;
     if (CFG::LDS_BYTES > 64 * 1024) {
@@ -251,30 +240,29 @@ template <int N, int MODE> static hipError_t launch_v2(const RangeArgs& a, hipSt
     int per_cu = (int)((160 * 1024) / CFG::LDS_BYTES);
     if (per_cu > 1024 / CFG::THREADS) per_cu = 1024 / CFG::THREADS;     // 128 VGPRs: 16 waves per CU
     if (per_cu < 1) per_cu = 1;
-    int grid = per_cu * num_cus();
-    if (const char* e = getenv("SARX_V2_WGS_PER_CU")) { const int w = atoi(e); grid = (w <= 0) ? groups : w * num_cus(); }
-    if (grid > groups) grid = groups;
+    int grid = persistent_grid(per_cu, cus, groups);
+    if (const char* e = getenv("SARX_V2_WGS_PER_CU")) { const int w = atoi(e); grid = (w <= 0) ? groups : persistent_grid(w, cus, groups); }
     hipLaunchKernelGGL(k, dim3(grid), dim3(CFG::THREADS), CFG::LDS_BYTES, st, a);
     return hipGetLastError();
 }
-template <int N> static hipError_t launch_v2_mode(int mode, const RangeArgs& a, hipStream_t st) {
+template <int N> static hipError_t launch_v2_mode(int mode, const RangeArgs& a, int cus, hipStream_t st) {
     switch (mode) {
-        case RG_FFT: return launch_v2<N, RG_FFT>(a, st);
-        case RG_IFFT: return launch_v2<N, RG_IFFT>(a, st);
-        case RG_FFT_PHI2: return launch_v2<N, RG_FFT_PHI2>(a, st);
-        case RG_IFFT_PHI3: return launch_v2<N, RG_IFFT_PHI3>(a, st);
-        case RG_FUSED: return launch_v2<N, RG_FUSED>(a, st);
+        case RG_FFT: return launch_v2<N, RG_FFT>(a, cus, st);
+        case RG_IFFT: return launch_v2<N, RG_IFFT>(a, cus, st);
+        case RG_FFT_PHI2: return launch_v2<N, RG_FFT_PHI2>(a, cus, st);
+        case RG_IFFT_PHI3: return launch_v2<N, RG_IFFT_PHI3>(a, cus, st);
+        case RG_FUSED: return launch_v2<N, RG_FUSED>(a, cus, st);
     }
     return hipErrorInvalidValue;
 }
 
 bool range_v2_supported(int n_rg) { return n_rg == 4096 || n_rg == 8192 || n_rg == 16384; }
 
-hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, hipStream_t st) {
+hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st) {
     switch (n_rg) {
-        case 4096: return launch_v2_mode<4096>(mode, a, st);
-        case 8192: return launch_v2_mode<8192>(mode, a, st);
-        case 16384: return launch_v2_mode<16384>(mode, a, st);
+        case 4096: return launch_v2_mode<4096>(mode, a, cus, st);
+        case 8192: return launch_v2_mode<8192>(mode, a, cus, st);
+        case 16384: return launch_v2_mode<16384>(mode, a, cus, st);
     }
     return hipErrorInvalidValue;
 }

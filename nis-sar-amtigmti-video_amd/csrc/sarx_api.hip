@@ -30,29 +30,61 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    std::string path;      // file the symbols came from
+    int version = 0;       // ncclGetVersion of that file
 };
 static RcclApi g_rccl;
+// RCCL must be the build that belongs to the HIP runtime this process runs on: a process that imported torch first runs
+// on torch's bundled libamdhip64 (soname libamdhip64.so.7, same as /opt/rocm's, so the loader hands it to libsarx too)
+// and must take torch's bundled librccl; a plain C / ctypes process runs on /opt/rocm's runtime and takes /opt/rocm's
+// librccl.  So: SARX_RCCL_PATH if set, else librccl from the directory of the loaded HIP runtime, else whatever
+// librccl.so.1 is already mapped, else the loader's search path.  The six entry points used are ABI-stable across
+// RCCL 2.2x; path and version are reported by sarx_rccl_info so a run states what it gathered with.
 static bool load_rccl(std::string& err) {
     if (g_rccl.lib) return true;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) { err = std::string("dlopen librccl: ") + dlerror(); return false; }
+    void* h = nullptr;
+    std::string tried;
+    auto attempt = [&](const std::string& name, int extra) {
+        if (h || name.empty()) return;
+        h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL | extra);
+        if (!h) tried += name + "; ";
+    };
+    if (const char* e = getenv("SARX_RCCL_PATH")) attempt(e, 0);
+    Dl_info di;
+    if (!h && dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash);
+            attempt(dir + "/librccl.so.1", 0);
+            attempt(dir + "/librccl.so", 0);
+        }
+    }
+    attempt("librccl.so.1", RTLD_NOLOAD);
+    attempt("librccl.so.1", 0);
+    attempt("librccl.so", 0);
+    if (!h) { err = "dlopen librccl failed (tried " + tried + ")"; return false; }
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(h, "ncclGetVersion");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         err = "librccl lacks a required symbol";
         dlclose(h);
         return false;
     }
+    if (dladdr((void*)g_rccl.GetUniqueId, &di) && di.dli_fname) g_rccl.path = di.dli_fname;
+    if (g_rccl.GetVersion) g_rccl.GetVersion(&g_rccl.version);
     g_rccl.lib = h;
     return true;
 }
 
 struct sarx_ctx {
     int device = -1;
+    int cus = 256;                     // compute units of this device (persistent grids are sized from it)
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev[N_EVENTS] = {};
@@ -135,6 +167,7 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
         return fail(nullptr, SARX_ERR_UNSUPPORTED, "device %d is %s; libsarx is built for gfx950 only", device_id, prop.gcnArchName);
     sarx_ctx* c = new sarx_ctx();
     c->device = device_id;
+    if (prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
     if (const char* e2 = getenv("SARX_RANGE_IMPL")) c->range_impl = (e2[0] == 'v') ? atoi(e2 + 1) : atoi(e2);
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
@@ -172,6 +205,8 @@ int sarx_destroy(sarx_ctx* c) {
     delete c;
     return SARX_OK;
 }
+
+int sarx_persistent_grid(int wgs_per_cu, int cus, int work_items) { return persistent_grid(wgs_per_cu, cus, work_items); }
 
 int sarx_device_info(sarx_ctx* c, char* name, size_t name_len, int* cus, uint64_t* hbm, char* arch, size_t arch_len) {
     if (!c) return fail(nullptr, SARX_ERR_INVALID, "ctx is NULL");
@@ -211,6 +246,22 @@ int sarx_memcpy_d2h(sarx_ctx* c, void* d, const void* s, size_t n) {
 int sarx_memcpy_d2d(sarx_ctx* c, void* d, const void* s, size_t n) {
     NEED_CTX(c);
     HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream));
+    return SARX_OK;
+}
+int sarx_memcpy2d_d2h(sarx_ctx* c, void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height) {
+    NEED_CTX(c);
+    if (!d || !s || width > dpitch || width > spitch) return fail(c, SARX_ERR_INVALID, "bad 2-D copy arguments");
+    if (!width || !height) return SARX_OK;
+    HIPCHK(c, hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SARX_OK;
+}
+int sarx_memcpy2d_h2d(sarx_ctx* c, void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height) {
+    NEED_CTX(c);
+    if (!d || !s || width > dpitch || width > spitch) return fail(c, SARX_ERR_INVALID, "bad 2-D copy arguments");
+    if (!width || !height) return SARX_OK;
+    HIPCHK(c, hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SARX_OK;
 }
 int sarx_memset(sarx_ctx* c, void* d, int v, size_t n) { NEED_CTX(c); HIPCHK(c, hipMemsetAsync(d, v, n, c->stream)); return SARX_OK; }
@@ -369,8 +420,8 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
                     (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 16384 && mode != RG_FUSED));
     // impl 3 (default for the fused launch at 16384): wave-private sub-transforms
     if (mode == RG_FUSED && range_fused_wl_supported(p->n_rg) && (c->range_impl == 3 || c->range_impl == 0))
-        return launch_range_fused_wl(a, c->stream);
-    return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
+        return launch_range_fused_wl(a, c->cus, c->stream);
+    return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->cus, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
 }
 
 // azimuth FFT (+epilogue) in -> out via tmp (tmp unused for single-step sizes); in is not modified
@@ -556,6 +607,12 @@ int sarx_ati_dpca_dev(sarx_ctx* c, const void* s1, const void* s2, size_t n, dou
     NEED_CTX(c);
     if (!s1 || !s2 || !o || !o->ati_phase || !o->slc1_mag || !o->dpca_mag) return fail(c, SARX_ERR_INVALID, "NULL required pointer");
     if (n == 0) { if (max_mag) *max_mag = 0; if (sum2) sum2[0] = sum2[1] = 0; return SARX_OK; }
+    {   // the kernel moves 16 bytes per lane and plane
+        const void* ptrs[] = {s1, s2, o->ati_phase, o->slc1_mag, o->dpca_mag, o->ati_interf, o->dpca_diff, o->slc2_mag,
+                              o->slc1_phase, o->slc2_phase, o->dpca_phase};
+        for (const void* q : ptrs)
+            if (((uintptr_t)q) & 15) return fail(c, SARX_ERR_INVALID, "ATI/DPCA buffers must be 16-byte aligned");
+    }
     AtiArgs a{};
     a.s1 = (const float2*)s1; a.s2 = (const float2*)s2; a.n = n;
     a.cal_c = (float)cos(cal_phase); a.cal_s = (float)sin(cal_phase);
@@ -572,6 +629,31 @@ int sarx_ati_dpca_dev(sarx_ctx* c, const void* s1, const void* s2, size_t n, dou
         if (max_mag) *max_mag = h[0];
         if (sum2) { sum2[0] = h[1]; sum2[1] = h[2]; }
     }
+    return SARX_OK;
+}
+
+int sarx_ati_stats(sarx_ctx* c, double* max_mag, double* sum2) {
+    NEED_CTX(c);
+    double h[3];
+    HIPCHK(c, hipMemcpyAsync(h, c->ati_out3, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (max_mag) *max_mag = h[0];
+    if (sum2) { sum2[0] = h[1]; sum2[1] = h[2]; }
+    return SARX_OK;
+}
+
+int sarx_mask_phase_frac_dev(sarx_ctx* c, const float* phase, const float* mag, size_t n, float frac, float* out) {
+    NEED_CTX(c);
+    if (!phase || !mag || !out) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (n == 0) return SARX_OK;
+    HIPCHK(c, launch_mask_phase_frac(phase, mag, n, frac, c->ati_out3, out, c->stream));
+    return SARX_OK;
+}
+
+int sarx_magnitude_dev(sarx_ctx* c, const void* in, float* out, size_t n) {
+    NEED_CTX(c);
+    if (!in || !out) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (n) HIPCHK(c, launch_magnitude((const float2*)in, out, n, c->stream));
     return SARX_OK;
 }
 
@@ -756,6 +838,14 @@ int sarx_comm_unique_id(void* id_out) {
     ncclResult_t r = g_rccl.GetUniqueId(&id);
     if (r != ncclSuccess) return fail(nullptr, SARX_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     memcpy(id_out, &id, sizeof id);
+    return SARX_OK;
+}
+int sarx_rccl_info(char* path, size_t path_len, int* version, int* header_version) {
+    std::string err;
+    if (!load_rccl(err)) return fail(nullptr, SARX_ERR_COMM, "%s", err.c_str());
+    if (path && path_len) snprintf(path, path_len, "%s", g_rccl.path.c_str());
+    if (version) *version = g_rccl.version;
+    if (header_version) *header_version = NCCL_VERSION_CODE;
     return SARX_OK;
 }
 int sarx_comm_init(sarx_ctx* c, const void* id, int n_ranks, int rank) {

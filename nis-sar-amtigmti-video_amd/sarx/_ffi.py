@@ -60,7 +60,10 @@ SIGNATURES = {
     "sarx_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    "sarx_memcpy2d_h2d": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "sarx_memset": (_i, [_vp, _vp, _i, _sz]),
+    "sarx_persistent_grid": (_i, [_i, _i, _i]),
     "sarx_sync": (_i, [_vp]),
     "sarx_event_record": (_i, [_vp, _i]),
     "sarx_event_elapsed_ms": (_i, [_vp, _i, _i, _P(_f)]),
@@ -78,6 +81,9 @@ SIGNATURES = {
     "sarx_rda_focus_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sarx_rda_axes": (_i, [_vp, _vp, _vp, _vp]),
     "sarx_ati_dpca_dev": (_i, [_vp, _vp, _vp, _sz, _d, _P(AtiOutputs), _P(_d), _P(_d)]),
+    "sarx_ati_stats": (_i, [_vp, _P(_d), _P(_d)]),
+    "sarx_mask_phase_frac_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
+    "sarx_magnitude_dev": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_mask_phase_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
     "sarx_corner_turn_dev": (_i, [_vp, _vp, _vp, _i, _i]),
     "sarx_multilook_dev": (_i, [_vp, _vp, _vp, _i, _i, _i]),
@@ -93,6 +99,7 @@ SIGNATURES = {
     "sarx_tdbp_focus_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp]),
     "sarx_tdbp_focus_host": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _vp]),
     "sarx_comm_unique_id": (_i, [_vp]),
+    "sarx_rccl_info": (_i, [C.c_char_p, _sz, _P(_i), _P(_i)]),
     "sarx_comm_init": (_i, [_vp, _vp, _i, _i]),
     "sarx_allgather_dev": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_comm_sync": (_i, [_vp]),

@@ -74,14 +74,53 @@ class TorchStackComm:
         pass
 
 
-class RcclStackComm:
-    """Device all-gather through libsarx (RCCL).  The unique id is created on rank 0 and
-    handed to the other ranks by ``bootstrap`` (any broadcast of 128 bytes, e.g. a gloo group)."""
+def agree_on_rccl(ctx, world, rank, dist=None, log=None):
+    """Collective RCCL bootstrap that cannot strand a rank: every rank reaches every rendezvous step whatever failed
+    where.  Rank 0 creates the unique id (None after a failure), the id is broadcast over the torch.distributed
+    (gloo) group, every rank tries ncclCommInitRank, and a MIN-reduced flag decides for all ranks alike.
+    Returns True when the communicator is up on every rank; otherwise False on every rank (any half-made communicator
+    is destroyed) and the caller falls back or raises - on all ranks together."""
+    uid, ok = None, 1
+    if rank == 0:
+        try:
+            uid = ctx.comm_unique_id()
+        except Exception as exc:                          # noqa: BLE001
+            if log:
+                log(f"RCCL unique id failed: {exc}")
+    if dist is not None and world > 1:
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)            # every rank takes part, also after a failure on rank 0
+        uid = box[0]
+    made = False
+    if uid is None:
+        ok = 0
+    else:
+        try:
+            ctx.comm_init(uid, world, rank)
+            made = True
+        except Exception as exc:                          # noqa: BLE001
+            ok = 0
+            if log:
+                log(f"RCCL init failed on rank {rank}: {exc}")
+    if dist is not None and world > 1:
+        import torch
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok and made:
+        ctx.lib.sarx_comm_destroy(ctx.h)
+    return bool(ok)
 
-    def __init__(self, ctx, world, rank, bootstrap):
-        uid = ctx.comm_unique_id() if rank == 0 else None
-        uid = bootstrap(uid)
-        ctx.comm_init(uid, world, rank)
+
+class RcclStackComm:
+    """Device all-gather through libsarx (RCCL).  ``dist``: an initialised torch.distributed module (gloo group) used
+    only to hand the 128-byte unique id around and to agree on success; with world == 1 it may be None.  If the
+    bootstrap fails anywhere, every rank raises SarxError together (nobody is left waiting in a rendezvous)."""
+
+    def __init__(self, ctx, world, rank, dist=None, log=None):
+        from ._ffi import SarxError
+        if not agree_on_rccl(ctx, world, rank, dist, log):
+            raise SarxError(-5, "RCCL bootstrap failed on at least one rank (all ranks raise together)")
         self.ctx, self.world, self.rank = ctx, world, rank
 
     def all_gather_dev(self, d_slot, d_recv_block, nbytes):
@@ -91,24 +130,153 @@ class RcclStackComm:
     def finish(self):
         self.ctx.comm_sync()
 
+    def close(self):
+        self.ctx.lib.sarx_comm_destroy(self.ctx.h)
 
-def run_batch_host(frame_ids_all, world, rank, process_frame, comm):
+
+def run_batch_host(frame_ids_all, world, rank, process_frame, comm, slot_shape=None):
     """Reference-shaped driver on host arrays (CPU tests, small jobs).
 
     process_frame(f) -> 2-D float array (the frame's stack slot).  Every rank
-    takes part in every round; ranks without a frame in the last round send zeros.
+    takes part in every round; ranks without a frame in a round send zeros.  A rank that owns no frame at all
+    (more ranks than frames) sizes its pad slots from ``slot_shape``; without it the shape is agreed over the
+    transport first (one extra tiny gather), so no rank ever raises while its peers wait in a collective.
     """
     n = len(frame_ids_all)
     mine = shard_frames(n, world, rank)
-    blocks, shape = [], None
+    blocks, shape = [], tuple(slot_shape) if slot_shape is not None else None
+    first = None
+    if shape is None:
+        if mine:
+            first = np.asarray(process_frame(frame_ids_all[mine[0]]), dtype=np.float32)
+            shape = first.shape
+        if world > n:                                     # somebody owns nothing: agree on the shape
+            mine_shape = np.array(shape if shape is not None else (0, 0), dtype=np.float32)[None, :]
+            shapes = comm.all_gather(mine_shape)
+            shape = tuple(int(v) for v in shapes.reshape(world, 2).max(axis=0))
     for i in range(rounds(n, world)):
         if i < len(mine):
-            slot = np.asarray(process_frame(frame_ids_all[mine[i]]), dtype=np.float32)
-            shape = slot.shape
+            slot = first if (i == 0 and first is not None) else np.asarray(process_frame(frame_ids_all[mine[i]]), dtype=np.float32)
         else:
-            if shape is None:
-                raise ValueError("a rank without any frame cannot size its pad slot")
             slot = np.zeros(shape, dtype=np.float32)
         blocks.append(comm.all_gather(slot))
     comm.finish()
     return stack_from_rounds(blocks, n)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 on the device: a VideoSAR batch of two-channel scenes, frame f -> rank f mod N
+# ----------------------------------------------------------------------------------------------------------------
+STACKS = ("multilook", "magnitude")
+
+
+class TwoChannelBatch:
+    """n_frames two-channel [n x n] complex64 scenes (the processing section of sar_ati_dcpa_sim_csa.py:402-449 per
+    frame, frames independent as in sar_batch_sim.py:303-331), sharded frame f -> rank f mod world.
+
+    Per frame, all on the device and without a host round trip: CSA focus of both channels, ATI/DPCA products with
+    the fp64 phase-balance sum, the 5 % magnitude mask (threshold from the device-side max), and the frame's stack
+    slot:  stack="multilook": looks x looks mean of |slc1|^2 (1 MiB per 8192^2 frame - the display stack the
+    reference's batch script keeps, 512^2 per frame, sar_batch_sim.py:322);  stack="magnitude": |slc1| at full
+    resolution (256 MiB per 8192^2 frame: the configuration that loads xGMI).
+
+    The stack lives in one device buffer [rounds][world][slot]; a frame's slot is produced directly at its place
+    and each round is gathered IN PLACE (send = recv + rank * slot), so there is no send buffer to recycle and no
+    fence between compute and communication beyond stream order.  A rank without a frame in the last round zeroes its
+    slot before the gather (never a stale slot).  Transports: RCCL on the ctx's comm stream (overlaps the next
+    round's focusing), a torch.distributed (gloo) group through host memory (fallback / one-GPU rehearsal), or none
+    (world 1).
+    """
+
+    def __init__(self, ctx, n, n_frames, world=1, rank=0, stack="multilook", looks=16, rccl=False, host_comm=None,
+                 seed_base=1000, flags=None, mask_frac=0.05):
+        from . import _ffi, radar
+        from .engine import CsaPlan
+        if stack not in STACKS:
+            raise ValueError(f"stack must be one of {STACKS}")
+        if world > 1 and not rccl and host_comm is None:
+            raise ValueError("world > 1 needs a transport (rccl=True or host_comm)")
+        self.ctx, self.n, self.n_frames, self.world, self.rank = ctx, int(n), int(n_frames), int(world), int(rank)
+        self.stack_kind, self.looks, self.rccl, self.host_comm = stack, int(looks), bool(rccl), host_comm
+        self.seed_base, self.mask_frac = int(seed_base), float(mask_frac)
+        px = self.n * self.n
+        self.px = px
+        self.plan = CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE if flags is None else flags)
+        self.raw1, self.raw2, self.s1, self.s2 = (ctx.alloc(px * 8) for _ in range(4))
+        self.outs = {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
+        self.masked = ctx.alloc(px * 4)
+        self.slot_shape = (n // looks, n // looks) if stack == "multilook" else (n, n)
+        self.slot_bytes = self.slot_shape[0] * self.slot_shape[1] * 4
+        self.n_rounds = rounds(self.n_frames, self.world)
+        self.mine = shard_frames(self.n_frames, self.world, self.rank)
+        self.d_stack = ctx.alloc(self.slot_bytes * self.world * self.n_rounds)
+        self._host_stack = None
+
+    # -- one frame -------------------------------------------------------------------------------------------
+    def synth_frame(self, f):
+        """Stand-in for frame f's two echo channels: device-resident complex noise, seeds per (frame, channel)."""
+        self.ctx.fill_noise(self.raw1, self.px, self.seed_base + 2 * f)
+        self.ctx.fill_noise(self.raw2, self.px, self.seed_base + 2 * f + 1)
+
+    def focus_frame(self):
+        """raw1, raw2 -> s1, s2, ATI/DPCA planes, masked phase.  Only enqueues (no host synchronisation)."""
+        ctx = self.ctx
+        self.plan.focus_dev(self.raw1, self.s1)
+        self.plan.focus_dev(self.raw2, self.s2)
+        ctx.ati_dpca(self.s1, self.s2, self.px, 0.0, self.outs, want_stats=False)
+        ctx.mask_phase_frac(self.outs["ati_phase"], self.outs["slc1_mag"], self.px, self.mask_frac, self.masked)
+
+    def _slot_ptr(self, i, r):
+        return self.d_stack.ptr + (i * self.world + r) * self.slot_bytes
+
+    def write_slot(self, dst_ptr):
+        ctx = self.ctx
+        if self.stack_kind == "multilook":
+            from ._ffi import check
+            check(ctx.lib.sarx_multilook_dev(ctx.h, self.s1.ptr, dst_ptr, self.n, self.n, self.looks), ctx.h)
+        else:
+            from ._ffi import check
+            check(ctx.lib.sarx_magnitude_dev(ctx.h, self.s1.ptr, dst_ptr, self.px), ctx.h)
+
+    # -- the batch ---------------------------------------------------------------------------------------------
+    def run(self):
+        """Focus this rank's frames and assemble the whole stack on every rank.  Returns after everything is
+        enqueued and (host transport only) gathered; call ctx.sync() to wait for the device."""
+        from ._ffi import check
+        ctx = self.ctx
+        for i in range(self.n_rounds):
+            mine_ptr = self._slot_ptr(i, self.rank)
+            if i < len(self.mine):
+                self.synth_frame(self.mine[i])
+                self.focus_frame()
+                self.write_slot(mine_ptr)
+            else:                                                   # pad round: zeros, never a stale slot
+                check(ctx.lib.sarx_memset(ctx.h, mine_ptr, 0, self.slot_bytes), ctx.h)
+            if self.world == 1:
+                continue
+            if self.rccl:                                           # in place: send = recv + rank * slot
+                check(ctx.lib.sarx_allgather_dev(ctx.h, mine_ptr, self._slot_ptr(i, 0), self.slot_bytes), ctx.h)
+            else:
+                slot = np.empty(self.slot_shape, dtype=np.float32)
+                check(ctx.lib.sarx_memcpy_d2h(ctx.h, slot.ctypes.data, mine_ptr, self.slot_bytes), ctx.h)
+                block = np.ascontiguousarray(self.host_comm.all_gather(slot))
+                check(ctx.lib.sarx_memcpy_h2d(ctx.h, self._slot_ptr(i, 0), block.ctypes.data, block.nbytes), ctx.h)
+        if self.rccl and self.world > 1:
+            ctx.comm_sync()
+
+    def stack(self, frames=None):
+        """The assembled [n_frames, H, W] float32 stack (or the listed frames of it) on the host."""
+        h, w = self.slot_shape
+        if frames is None:
+            return self.d_stack.download(np.float32, (self.n_rounds * self.world, h, w))[:self.n_frames]
+        out = np.empty((len(frames), h, w), dtype=np.float32)
+        from ._ffi import check
+        for k, f in enumerate(frames):
+            check(self.ctx.lib.sarx_memcpy_d2h(self.ctx.h, out[k].ctypes.data, self.d_stack.ptr + f * self.slot_bytes,
+                                               self.slot_bytes), self.ctx.h)
+        return out
+
+    def close(self):
+        for b in (self.raw1, self.raw2, self.s1, self.s2, self.masked, self.d_stack, *self.outs.values()):
+            b.release()
+        self.plan.close()

@@ -48,6 +48,26 @@ class DeviceBuffer:
         return out
 
 
+def download_block(ctx, ptr, ld_elems, row0, n_rows, col0, n_cols, dtype=np.complex64):
+    """Rows [row0, row0+n_rows) x columns [col0, col0+n_cols) of a row-major device image with leading dimension
+    ``ld_elems`` (strided copy, blocking): how tests sample columns of a full-size image without downloading it."""
+    item = np.dtype(dtype).itemsize
+    out = np.empty((n_rows, n_cols), dtype=dtype)
+    src = ptr + (int(row0) * int(ld_elems) + int(col0)) * item
+    check(ctx.lib.sarx_memcpy2d_d2h(ctx.h, out.ctypes.data, n_cols * item, src, int(ld_elems) * item, n_cols * item,
+                                    int(n_rows)), ctx.h)
+    return out
+
+
+def upload_block(ctx, ptr, ld_elems, row0, col0, block):
+    """Inverse of download_block: writes a host [n_rows x n_cols] block into the device image."""
+    block = np.ascontiguousarray(block)
+    item = block.dtype.itemsize
+    dst = ptr + (int(row0) * int(ld_elems) + int(col0)) * item
+    check(ctx.lib.sarx_memcpy2d_h2d(ctx.h, dst, int(ld_elems) * item, block.ctypes.data, block.shape[1] * item,
+                                    block.shape[1] * item, block.shape[0]), ctx.h)
+
+
 class DeviceArray:
     """A row-major 2-D complex64 array living in a DeviceBuffer: what the echo generators return with ``device=True``
     and what the focusers accept in place of a NumPy array, so a scene can go from synthesis to products without
@@ -160,6 +180,20 @@ class Context:
     def mask_phase(self, phase, mag, n, thr, out):
         check(self.lib.sarx_mask_phase_dev(self.h, phase.ptr, mag.ptr, int(n), float(thr), out.ptr), self.h)
 
+    def mask_phase_frac(self, phase, mag, n, frac, out):
+        """Mask with thr = frac * max|slc1| of the most recent ati_dpca launch, taken on the device (no host sync)."""
+        check(self.lib.sarx_mask_phase_frac_dev(self.h, phase.ptr, mag.ptr, int(n), float(frac), out.ptr), self.h)
+
+    def ati_stats(self):
+        """(max|slc1|, sum slc1*conj(slc2)) of the most recent ati_dpca launch (blocking)."""
+        mx = C.c_double()
+        sm = (C.c_double * 2)()
+        check(self.lib.sarx_ati_stats(self.h, C.byref(mx), sm), self.h)
+        return mx.value, complex(sm[0], sm[1])
+
+    def magnitude(self, src, dst, n):
+        check(self.lib.sarx_magnitude_dev(self.h, src.ptr, dst.ptr, int(n)), self.h)
+
     def ati_dpca(self, slc1, slc2, n, cal_phase, outs, want_stats=True):
         """outs: dict name -> DeviceBuffer for fields of sarx_ati_outputs."""
         o = _ffi.AtiOutputs()
@@ -173,6 +207,14 @@ class Context:
         return (mx.value, complex(sm[0], sm[1])) if want_stats else None
 
     # -- RCCL --
+    @staticmethod
+    def rccl_info():
+        """{'path', 'version', 'header_version'} of the RCCL the collectives run on (loads it)."""
+        path = C.create_string_buffer(1024)
+        ver, hdr = C.c_int(), C.c_int()
+        check(_ffi.load().sarx_rccl_info(path, 1024, C.byref(ver), C.byref(hdr)), None)
+        return {"path": path.value.decode(), "version": ver.value, "header_version": hdr.value}
+
     @staticmethod
     def comm_unique_id():
         buf = C.create_string_buffer(_ffi.COMM_ID_BYTES)
@@ -273,4 +315,4 @@ def default_context(device_id=0):
     return c
 
 
-__all__ = ["Context", "CsaPlan", "DeviceBuffer", "SarxError", "default_context"]
+__all__ = ["Context", "CsaPlan", "DeviceBuffer", "SarxError", "default_context", "download_block", "upload_block"]

@@ -187,7 +187,8 @@ def tdbp_gpu(raw_t, pos_plat, vel_plat, t_start, num_samples, vel_focus, t_pulse
     n_p = len(t_pulses)
     key = (id(ctx), n_p, int(num_samples), int(nx), int(ny), k["C"], k["FC"], k["FS"], k["T_P"], k["K_RATE"])
     plan = _plans.get(key)
-    if plan is None:
+    if plan is None or plan.h is None:         # closed together with its Context: never reuse a dead handle
+        _plans.pop(key, None)
         if len(_plans) >= 4:
             _plans.pop(next(iter(_plans))).close()
         plan = _plans[key] = TdbpPlan(ctx, n_p, num_samples, nx, ny, k)

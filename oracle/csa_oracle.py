@@ -176,6 +176,59 @@ def sar_focus_csa_lean(phist, center_wavelength_m, pulse_width_sec, chirp_rate_h
 
 
 # ---------------------------------------------------------------------------
+# Sampled rows / columns of the chain, for scenes the full-array functions above cannot hold
+# (16384^2, 8192^2).  Range passes act on each azimuth bin's row alone (:278-382) and azimuth
+# passes on each range column alone (:233-274, :385), so a handful of rows / columns of a
+# device-resident image is checked exactly.  Same shift bookkeeping as sar_focus_csa.
+# ---------------------------------------------------------------------------
+def range_chain_rows(s1_rows, bins, n_az, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec,
+                     sample_rate_hz, prf_hz, platform_speed_mps, range_ref_m, t_start_fast):
+    """Passes 2 and 3 for the rows of the pass-1 output that belong to azimuth bins ``bins``
+    (natural fftfreq indices into an n_az-bin axis).  Returns (st2_rows, st3_rows), natural order."""
+    fft = np.fft
+    S = np.asarray(s1_rows, dtype=np.complex128)
+    n_rg = S.shape[1]
+    lam, Kr, Vr, R_ref = center_wavelength_m, chirp_rate_hzpsec, platform_speed_mps, range_ref_m
+    c = C_LIGHT
+    tau, fr, fa = csa_axes(n_az, n_rg, sample_rate_hz, prf_hz, t_start_fast)
+    D, Cs, _ = migration_factors(fa[np.asarray(bins)], lam, Vr, R_ref)
+    Dc, Csc = D[:, None], Cs[:, None]
+    tr = tau[None, :]
+    S = fft.fftshift(fft.fft(S, axis=1), axes=1)                                   # :278-281
+    fr_s = fft.fftshift(fr)[None, :]
+    S = S * np.exp(1j * (np.pi * fr_s**2 / (Kr * (1.0 + Csc)) + 4.0 * np.pi * R_ref * Csc * fr_s / c))   # :318-326
+    st2 = fft.ifftshift(S, axes=1)
+    S = fft.ifft(fft.ifftshift(S, axes=1), axis=1)                                 # :331
+    R_vec = c * tau / 2.0                                                          # :346
+    S = S * np.exp(1j * (4.0 * np.pi * R_vec[None, :] * Dc / lam
+                         - np.pi * Kr * Csc * (1.0 + Csc) * (tr - 2.0 * R_ref / c) ** 2))   # :359,375-382
+    return st2, S
+
+
+def azimuth_fft_cols(raw_cols, cols, n_rg, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec,
+                     sample_rate_hz, prf_hz, platform_speed_mps, range_ref_m, t_start_fast):
+    """Pass 1 (:233-274) for the range columns ``cols`` of an [n_az x n_rg] echo: raw_cols is
+    [n_az x len(cols)].  Returns the pass-1 output columns in natural azimuth-bin order."""
+    fft = np.fft
+    S = np.asarray(raw_cols, dtype=np.complex128)
+    n_az = S.shape[0]
+    lam, Kr, Vr, R_ref = center_wavelength_m, chirp_rate_hzpsec, platform_speed_mps, range_ref_m
+    tau, _, fa = csa_axes(n_az, n_rg, sample_rate_hz, prf_hz, t_start_fast)
+    S = fft.fftshift(fft.fft(S, axis=0), axes=0)                                   # :233-235
+    D, Cs, tau_ref = migration_factors(fft.fftshift(fa), lam, Vr, R_ref)
+    tr = tau[np.asarray(cols)][None, :]
+    S = S * np.exp(-1j * np.pi * Kr * Cs[:, None] * (tr - tau_ref[:, None]) ** 2)  # :272-274
+    return fft.ifftshift(S, axes=0)
+
+
+def azimuth_ifft_cols(s3_cols):
+    """Pass 4 (:385) for columns of the pass-3 output given in natural azimuth-bin order."""
+    fft = np.fft
+    S = fft.fftshift(np.asarray(s3_cols, dtype=np.complex128), axes=0)             # the array the reference holds
+    return fft.ifft(fft.ifftshift(S, axes=0), axis=0)
+
+
+# ---------------------------------------------------------------------------
 # A8  DPCA co-registration (sar_ati_dcpa_sim_csa.py:402-403)
 # ---------------------------------------------------------------------------
 def dpca_pulse_shift(raw_rx1, raw_rx2):

@@ -1,0 +1,34 @@
+"""One rank of a two-rank job for tests/test_gpu_batch64.py: sarx.batch.TwoChannelBatch on the GPU with the stack
+gathered through a gloo group (both ranks share the one GPU of the test box; RCCL refuses two ranks on one device,
+which is what the host transport is for)."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import conftest  # noqa: F401,E402
+import sarx  # noqa: E402
+from sarx.batch import TorchStackComm, TwoChannelBatch  # noqa: E402
+
+
+def main():
+    out, n, n_frames, stack = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo")
+    comm = TorchStackComm()
+    ctx = sarx.Context(0)
+    b = TwoChannelBatch(ctx, n, n_frames, comm.world, comm.rank, stack=stack, looks=16, host_comm=comm)
+    b.run()
+    ctx.sync()
+    h, w = b.slot_shape
+    whole = b.d_stack.download(np.float32, (b.n_rounds * comm.world, h, w))      # pad slots included
+    np.save(os.path.join(out, f"stack64_rank{comm.rank}.npy"), whole)
+    b.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

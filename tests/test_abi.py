@@ -29,13 +29,42 @@ def test_library_exports_every_symbol():
     lib = _ffi.load()
     for s in _header_symbols():
         assert hasattr(lib, s), s
-    assert lib.sarx_version() == 100
+    assert lib.sarx_version() == 200
 
 
 def test_struct_layouts():
     from sarx import _ffi
     assert C.sizeof(_ffi.RadarParams) == 8 * 8
     assert C.sizeof(_ffi.AtiOutputs) == 9 * C.sizeof(C.c_void_p)
+
+
+def test_persistent_grid_is_per_device_arithmetic():
+    """The persistent range kernels size their grid from the compute-unit count of the ctx being launched on
+    (sarx_persistent_grid), not from a process-wide cache: two devices with different CU counts get different grids."""
+    from sarx import _ffi
+    g = _ffi.load().sarx_persistent_grid
+    assert g(1, 256, 16384) == 256 and g(2, 256, 16384) == 512       # MI355X: fused range kernel, 32-point kernel
+    assert g(1, 304, 16384) == 304 and g(1, 64, 16384) == 64         # another device in the same process
+    assert g(2, 256, 64) == 64 and g(1, 256, 1) == 1                 # never more workgroups than lines
+    assert g(0, 0, 0) == 1 and g(-3, 256, 8) == 8                    # degenerate arguments still launch one workgroup
+
+
+def test_rccl_is_taken_from_the_hip_runtime_in_use():
+    """libsarx resolves librccl next to the HIP runtime the process runs on (torch's bundle after `import torch`,
+    /opt/rocm otherwise) and reports which file and version it got."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); {pre}import sarx, json; "
+            "print(json.dumps(sarx.Context.rccl_info()))" % os.path.join(ROOT, "nis-sar-amtigmti-video_amd"))
+    import json
+    plain = json.loads(subprocess.run([sys.executable, "-c", code.format(pre="")], capture_output=True, text=True,
+                                      check=True).stdout.strip().splitlines()[-1])
+    assert os.path.exists(plain["path"]) and "torch" not in plain["path"]
+    assert plain["version"] == plain["header_version"] > 20000         # /opt/rocm's RCCL is what the headers describe
+    with_torch = json.loads(subprocess.run([sys.executable, "-c", code.format(pre="import torch; ")],
+                                           capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    assert os.path.dirname(with_torch["path"]).endswith(os.path.join("torch", "lib"))
+    assert with_torch["version"] // 10000 == with_torch["header_version"] // 10000    # same major: the calls used are ABI-stable
 
 
 def _have_gpu():

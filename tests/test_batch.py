@@ -39,6 +39,41 @@ def test_stack_from_rounds_orders_and_drops_padding():
     assert batch.normalise_stack(np.zeros((2, 2, 2)))[1] == 1.0
 
 
+def test_run_batch_host_frameless_rank_and_pad_rounds():
+    """More ranks than frames: the rank that owns nothing sizes its zero slots from slot_shape (or from a shape
+    agreed over the transport) instead of raising while its peers wait in the collective."""
+    class FakeComm:                       # plays rank `me` of `world`; records what this rank sends each round
+        def __init__(self, world, me):
+            self.world, self.me, self.sent = world, me, []
+
+        def all_gather(self, slot):
+            self.sent.append(np.array(slot))
+            return np.stack([slot] * self.world)
+
+        def finish(self):
+            pass
+
+    frame = lambda f: np.full((3, 4), float(f + 1), np.float32)
+    c = FakeComm(4, 3)
+    st = batch.run_batch_host([0, 1], 4, 3, frame, c, slot_shape=(3, 4))       # rank 3 of 4 owns no frame of 2
+    assert st.shape == (2, 3, 4) and len(c.sent) == 1 and (c.sent[0] == 0).all() and c.sent[0].shape == (3, 4)
+    c = FakeComm(4, 3)                                                         # no slot_shape: one shape round first
+    c.all_gather_plain, first = c.all_gather, [True]
+
+    def gather_with_peer_shapes(slot):
+        if first[0]:                                                           # ranks 0, 1 own a frame and report (3, 4)
+            first[0] = False
+            c.sent.append(np.array(slot))
+            return np.array([[[3, 4]], [[3, 4]], [[0, 0]], [[0, 0]]], np.float32)
+        return c.all_gather_plain(slot)
+    c.all_gather = gather_with_peer_shapes
+    batch.run_batch_host([0, 1], 4, 3, frame, c)
+    assert c.sent[0].tolist() == [[0.0, 0.0]] and c.sent[1].shape == (3, 4) and (c.sent[1] == 0).all()
+    c = FakeComm(2, 1)
+    batch.run_batch_host([0, 1, 2], 2, 1, frame, c)                           # rank 1 of 2: frame 1, then a pad round
+    assert [float(x.max()) for x in c.sent] == [2.0, 0.0] and c.sent[1].shape == (3, 4)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

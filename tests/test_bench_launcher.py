@@ -1,0 +1,51 @@
+"""bench.py's own launcher: `python bench.py --gpus N` with WORLD_SIZE unset must start N ranks as child processes
+(before anything touches a GPU), and a --gpus that disagrees with WORLD_SIZE must fail instead of reporting 1 GPU.
+Runs on the CPU box: --dry-run stops every rank after the gloo rendezvous."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    env["OMP_NUM_THREADS"] = "1"
+    return subprocess.run([sys.executable, BENCH, *args], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bare_gpus_n_spawns_n_ranks():
+    r = _run(["--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "spawning 2 ranks" in r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["dry_run"] and line["n_gpus"] == 2
+    assert sorted(x["rank"] for x in line["ranks"]) == [0, 1]
+    assert sorted(x["local_rank"] for x in line["ranks"]) == [0, 1]
+    assert len({x["pid"] for x in line["ranks"]}) == 2 and all(x["world"] == 2 for x in line["ranks"])
+
+
+def test_single_rank_needs_no_launcher():
+    r = _run(["--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "spawning" not in r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    r = _run(["--gpus", "1", "--dry-run"])
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_gpus_disagreeing_with_world_size_is_an_error():
+    r = _run(["--gpus", "8", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2
+    assert "disagrees with WORLD_SIZE" in r.stderr
+    assert "{" not in r.stdout                                   # no JSON line with a wrong n_gpus
+
+
+def test_child_failure_propagates():
+    """A rank that fails (here: an unknown flag) makes the launcher exit non-zero."""
+    r = _run(["--gpus", "2", "--dry-run", "--no-such-flag"])
+    assert r.returncode != 0

@@ -1,0 +1,115 @@
+"""BASELINE config 5 - the 64-frame VideoSAR batch of two-channel 8192 x 8192 scenes - through the shared device
+driver (sarx.batch.TwoChannelBatch, what bench.py's `batch64` block times), on one GPU:
+slot f of the stack is bit-identical to the multilook of an independently focused frame f, slots are in frame order,
+pad slots are zeros, and a two-rank run (gloo transport, both ranks on the one GPU) assembles the same stack as one rank."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _independent_slot(sarx, ctx, n, f, stack, looks=16, seed_base=1000):
+    """Frame f focused on its own with fresh buffers and a fresh plan: channel 1's stack slot."""
+    from sarx import _ffi, radar
+    px = n * n
+    plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE)
+    raw, s1 = ctx.alloc(px * 8), ctx.alloc(px * 8)
+    ctx.fill_noise(raw, px, seed_base + 2 * f)
+    plan.focus_dev(raw, s1)
+    if stack == "multilook":
+        d = ctx.alloc((n // looks) ** 2 * 4)
+        ctx.multilook(s1, d, n, n, looks)
+        out = d.download(np.float32, (n // looks, n // looks))
+    else:
+        d = ctx.alloc(px * 4)
+        ctx.magnitude(s1, d, px)
+        out = d.download(np.float32, (n, n))
+    for b in (raw, s1, d):
+        b.release()
+    plan.close()
+    return out
+
+
+def test_config5_64_frames_two_channel_8192():
+    import sarx
+    from sarx.batch import TwoChannelBatch
+    ctx = sarx.default_context()
+    n, frames = 8192, 64
+    b = TwoChannelBatch(ctx, n, frames, stack="multilook")
+    b.run()
+    ctx.sync()
+    st = b.stack()
+    assert st.shape == (frames, n // 16, n // 16) and np.isfinite(st).all() and st.min() > 0
+    # the last frame's products are still in the driver's buffers: two different channels went through ATI/DPCA
+    mx, sm = ctx.ati_stats()
+    assert mx > 0 and abs(sm) > 0
+    masked = b.masked.download(np.float32, (8, n))
+    mag = b.outs["slc1_mag"].download(np.float32, (8, n))
+    ph = b.outs["ati_phase"].download(np.float32, (8, n))
+    thr = np.float32(mx) * np.float32(0.05)
+    np.testing.assert_array_equal(masked, np.where(mag > thr, ph, np.float32(0)))       # device-side threshold == host rule
+    assert float(b.outs["dpca_mag"].download(np.float32, (8, n)).max()) > 0             # channels differ
+    for f in (0, 1, 17, 40, 63):
+        np.testing.assert_array_equal(st[f], _independent_slot(sarx, ctx, n, f, "multilook"))
+    # frame order: every slot is its own frame (noise frames have distinct multilooked images)
+    sig = st.reshape(frames, -1)[:, :64]
+    assert len({s.tobytes() for s in sig}) == frames
+    b.run()                                                      # a second batch reproduces the stack bit for bit
+    ctx.sync()
+    np.testing.assert_array_equal(b.stack(frames=[5, 63]), st[[5, 63]])
+    b.close()
+
+
+def test_magnitude_stack_slot_is_full_resolution_channel_1():
+    import sarx
+    from sarx.batch import TwoChannelBatch
+    ctx = sarx.default_context()
+    n, frames = 2048, 5
+    b = TwoChannelBatch(ctx, n, frames, stack="magnitude")
+    b.run()
+    ctx.sync()
+    st = b.stack()
+    assert st.shape == (frames, n, n)
+    for f in (0, 4):
+        np.testing.assert_array_equal(st[f], _independent_slot(sarx, ctx, n, f, "magnitude"))
+    b.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("stack,n,frames", [("multilook", 2048, 5), ("magnitude", 1024, 4)])
+def test_two_ranks_one_gpu_equal_single_rank(tmp_path, stack, n, frames):
+    import sarx
+    from sarx.batch import TwoChannelBatch
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_batch64_worker.py"), str(tmp_path), str(n),
+           str(frames), stack]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    s0 = np.load(tmp_path / "stack64_rank0.npy")
+    s1 = np.load(tmp_path / "stack64_rank1.npy")
+    np.testing.assert_array_equal(s0, s1)                        # every rank holds the whole stack
+    ctx = sarx.default_context()
+    b = TwoChannelBatch(ctx, n, frames, stack=stack)
+    b.run()
+    ctx.sync()
+    single = b.stack()
+    b.close()
+    rounds = -(-frames // 2)
+    assert s0.shape[0] == 2 * rounds
+    np.testing.assert_array_equal(s0[:frames], single)           # N-rank stack == 1-rank stack, bit for bit, frame order
+    assert (s0[frames:] == 0).all()                              # the pad slot of the last round is zeros, not a stale slot

@@ -263,7 +263,7 @@ def test_rccl_allgather_single_rank(sx, ctx):
     from sarx.batch import RcclStackComm
     x = np.arange(1 << 16, dtype=np.float32)
     d_s, d_r = ctx.to_device(x), ctx.alloc(x.nbytes)
-    comm = RcclStackComm(ctx, 1, 0, bootstrap=lambda uid: uid)
+    comm = RcclStackComm(ctx, 1, 0)
     comm.all_gather_dev(d_s, d_r, x.nbytes)
     comm.finish()
     np.testing.assert_array_equal(d_r.download(np.float32, x.shape), x)

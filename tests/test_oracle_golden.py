@@ -38,6 +38,30 @@ def test_stages_are_consistent():
     assert s1.shape == s2.shape == s3.shape == (128, 128)
 
 
+@pytest.mark.parametrize("tag", ["csa_96x80", "csa_128x512", "csa_refconst_128x256"])
+def test_sampled_row_and_column_helpers_compose_to_the_reference(tag):
+    """The per-row / per-column restatements used at 16384^2 and 8192^2, chained over every row and column (in
+    shuffled order, in pieces), give the reference's own image."""
+    g = load_golden(tag + ".npz")
+    raw, args = g["phist"], g["args"]
+    n_az, n_rg = raw.shape
+    rng = np.random.default_rng(0)
+    s1 = np.empty((n_az, n_rg), np.complex128)
+    for cols in np.array_split(rng.permutation(n_rg), 3):
+        s1[:, cols] = orc.azimuth_fft_cols(raw[:, cols], cols, n_rg, *args)
+    s3 = np.empty_like(s1)
+    for bins in np.array_split(rng.permutation(n_az), 4):
+        s3[bins] = orc.range_chain_rows(s1[bins], bins, n_az, *args)[1]
+    img = np.empty_like(s1)
+    for cols in np.array_split(rng.permutation(n_rg), 2):
+        img[:, cols] = orc.azimuth_ifft_cols(s3[:, cols])
+    assert orc.rel_l2(img.T, g["img_T"]) < 1e-12
+    _, _, _, (t1, t2, t3, _) = orc.sar_focus_csa(raw, *args, return_stages=True)
+    assert orc.rel_l2(s1, t1) < 1e-13 and orc.rel_l2(s3, t3) < 1e-13
+    bins = np.array([0, 1, n_az // 2 - 1, n_az // 2, n_az - 1])
+    assert orc.rel_l2(orc.range_chain_rows(t1[bins], bins, n_az, *args)[0], t2[bins]) < 1e-13
+
+
 def test_digest_1024():
     g = load_golden("csa_digest_1024.npz")
     raw, k = orc.point_scene(1024, 1024, seed=int(g["seed"]), clutter_db=float(g["clutter_db"]))
