@@ -267,7 +267,7 @@ def main():
     # HBM bytes per launch: PMC counters cannot be read inside this process; the figure is REPLAYED from the separate
     # rocprofv3 --pmc passes kept under profiles/ (tools/pmc_traffic.sh), and labelled as such
     traffic, traffic_src = None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r02_pmc_range_kernels.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 pmc = json.load(fh)

@@ -137,10 +137,11 @@ int sarx_rda_plan_destroy(sarx_rda_plan* plan);
  * range-Doppler map (:399), map after RCMC (:427), each [n_pulses x n_ranges]. */
 int sarx_rda_focus_host(sarx_rda_plan* plan, const void* phist_pulse_major_host, float* image_mag_host,
                         void* range_compressed_host, void* range_doppler_host, void* range_doppler_rcmc_host);
-/* the same with the pulses already in device memory (d_phist_pulse_major, e.g. from the echo kernels); outputs are
- * host buffers as above, blocking */
-int sarx_rda_focus_dev(sarx_rda_plan* plan, const void* d_phist_pulse_major, float* image_mag_host,
-                       void* range_compressed_host, void* range_doppler_host, void* range_doppler_rcmc_host);
+/* device in / device out, asynchronous on the ctx stream: d_image_mag [n_pulses x n_ranges] fp32 is written by the last
+ * launch itself; the optional complex64 maps (NULL = skip) are device-to-device copies of the plan's buffers.  Nothing
+ * is downloaded and nothing blocks. */
+int sarx_rda_focus_dev(sarx_rda_plan* plan, const void* d_phist_pulse_major, float* d_image_mag,
+                       void* d_range_compressed, void* d_range_doppler, void* d_range_doppler_rcmc);
 /* range_axis_centered[n_ranges] (:443-444), cross_range_m[n_pulses] (:442), doppler_freq[n_pulses] (:402-405) */
 int sarx_rda_axes(const sarx_rda_plan* plan, double* range_axis_centered, double* cross_range_m, double* doppler_freq);
 

@@ -14,7 +14,9 @@ enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_S
                   AZ_EPI_TWIDDLE_PADIN = 7,   // inputs from a smaller [io_rows x io_cols] array (ld io_ld), zero outside, * rowvec[input row]; then TWIDDLE
                   AZ_EPI_CROPOUT = 8,
                   AZ_EPI_TWIDDLE_ROWSIN = 9,  // TWIDDLE, but input rows >= io_rows are zeros that are not read (chirp-z padding)
-                  AZ_EPI_SCALE_ROWSOUT = 10 };  // SCALE, but output rows >= io_rows are not written (only the cropped part is used)       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
+                  AZ_EPI_SCALE_ROWSOUT = 10,
+                  AZ_EPI_CROPOUT_PHI1 = 11,
+                  AZ_EPI_CROPOUT_MAG = 12 };    // CROPOUT, but the magnitude goes to out_mag (fp32) instead of the complex value to out   // CROPOUT, then * Phi_1(output row, col): the forward azimuth chirp-z ends in the CSA's first phase  // SCALE, but output rows >= io_rows are not written (only the cropped part is used)       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
 
 struct RangeArgs {
     const float2* in;
@@ -30,7 +32,13 @@ struct RangeArgs {
     int n_az;
     const float2* mulvec; // RG_FFT only, optional: out[line][k] *= mulvec[(line % mul_period) * n_rg + k]
     int mul_period;
+    // line -> image row.  row_inner == 0: the launch covers rows 0 .. n_az-1.  Otherwise line i of the n_az lines of this
+    // launch is row  row0 + i % row_inner + (i / row_inner) * row_stride  (the rows of a group of azimuth tiles: slab mode)
+    int row0, row_inner, row_stride;
 };
+__host__ __device__ inline int range_row(const RangeArgs& a, int line) {
+    return a.row_inner ? a.row0 + line % a.row_inner + (line / a.row_inner) * a.row_stride : line;
+}
 
 struct AzArgs {
     const float2* in;
@@ -41,13 +49,17 @@ struct AzArgs {
     const float2* rowvec; // AZ_EPI_ROWVEC / CROPOUT: per output row; TWIDDLE_PADIN: per input row (optional)
     size_t io_ld;         // TWIDDLE_PADIN / CROPOUT: leading dimension and extents of the smaller array
     int io_rows, io_cols;
+    int io_shift_in;      // TWIDDLE_PADIN: sequence element r is source row (r + io_shift_in) mod io_rows (fftshift bookkeeping)
+    int io_shift_out;     // CROPOUT*: sequence element r goes to destination row (r + io_shift_out) mod io_rows
+    float* out_mag;       // CROPOUT_MAG: [io_rows x io_cols] fp32 magnitudes (leading dimension io_ld)
     int valid_len;        // TWCOL / PROCOL (split lines): only the first valid_len samples of a line are read (rest = 0) / written; 0 = all
     double dt, t_start;
     float scale;          // 1/n_az for the inverse's last step
     float tw_scale;       // 1/M for the column-indexed twiddles of the 32768-point line split
     int n_rg;
-    // row of tile element m for tile q: q*q_stride + m*m_stride
+    // row of tile element m for tile q: q*q_stride + m*m_stride;  q = blockIdx.y + q0 (a launch may cover a range of tiles)
     int in_q_stride, in_m_stride, out_q_stride, out_m_stride;
+    int q0;
 };
 
 // Grid of a persistent kernel: wgs_per_cu resident workgroups on each of `cus` compute units, never more workgroups
@@ -68,8 +80,17 @@ hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, int cus,
 // range_fused_wl.hip: fused FFT.Phi2.IFFT.Phi3 at 16384 with wave-private sub-transforms
 bool range_fused_wl_supported(int n_rg);
 hipError_t launch_range_fused_wl(const RangeArgs& a, int cus, hipStream_t st);
+// range_mixed.hip: direct mixed-radix lines (13200 = 24 * 22 * 25, the reference's native range extent), all modes
+bool range_mixed_supported(int n_rg);
+hipError_t launch_range_mixed(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st);
 // r: FFT length of the tile (2..128), w: tile width in range samples (16 or 32), nq: tiles along azimuth
 hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int nq, hipStream_t st);
+
+// Middle launch of a two-step chirp-z column transform of length M = ra * s (general.hip): tile q holds rows q*s + m
+// (m < s) of a [M x n_rg] array; FFT_s over m gives bins q + ra*k2, times bhat[q + ra*k2] (a.rowvec, natural order),
+// inverse FFT_s, times the conjugate four-step twiddle W_M^(+q m) (a.tw_scale = 1/M), in place.  The forward
+// transform's second step and the inverse transform's first step on one HBM round trip.
+hipError_t launch_az_conv(int s, int ra, const AzArgs& a, hipStream_t st);
 
 // products.hip
 struct AtiArgs {

@@ -30,9 +30,10 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
 
     const int r_in_wg = threadIdx.x / T;
     const int t = threadIdx.x % T;
-    int row = blockIdx.x * CFG::ROWS + r_in_wg;
-    const bool live = row < a.n_az;
-    if (!live) row = a.n_az - 1;                    // keep barriers uniform
+    int line = blockIdx.x * CFG::ROWS + r_in_wg;
+    const bool live = line < a.n_az;
+    if (!live) line = a.n_az - 1;                   // keep barriers uniform
+    const int row = range_row(a, line);
     cf* my_lds = lds + r_in_wg * CFG::LDS_PER_ROW;
     const cf* __restrict__ src = a.in + (size_t)row * N;
     cf* __restrict__ dst = a.out + (size_t)row * N;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
     const int c = threadIdx.x % W;
     const int t = threadIdx.x / W;
     const int col = blockIdx.x * W + c;
-    const int q = blockIdx.y;
+    const int q = blockIdx.y + a.q0;
     const size_t in_base = (size_t)q * a.in_q_stride;
     const size_t out_base = (size_t)q * a.out_q_stride;
 
@@ -212,7 +213,9 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             if constexpr (EPI == AZ_EPI_TWIDDLE_PADIN) {   // copy-in, zero padding and pre-chirp of general.hip fused into the first step
                 x = make_float2(0.f, 0.f);
                 if (rowi < (size_t)a.io_rows && col < a.io_cols) {
-                    x = a.in[rowi * a.io_ld + col];
+                    size_t srow = rowi + (size_t)a.io_shift_in;             // circular row shift of the source (0 = none)
+                    if (srow >= (size_t)a.io_rows) srow -= (size_t)a.io_rows;
+                    x = a.in[srow * a.io_ld + col];
                     if (a.rowvec) x = cmul(x, a.rowvec[rowi]);
                 }
             } else if constexpr (EPI == AZ_EPI_TWIDDLE_ROWSIN) {
@@ -260,11 +263,16 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                 x.x *= a.scale; x.y *= a.scale;
             } else if constexpr (EPI == AZ_EPI_ROWVEC) {
                 x = cmul(x, a.rowvec[rowo]);
-            } else if constexpr (EPI == AZ_EPI_CROPOUT) {  // post-chirp, scale and crop of general.hip fused into the last step
+            } else if constexpr (EPI == AZ_EPI_CROPOUT || EPI == AZ_EPI_CROPOUT_PHI1 || EPI == AZ_EPI_CROPOUT_MAG) {
+                // post-chirp, scale and crop of general.hip fused into the last step
                 if (rowo < (size_t)a.io_rows && col < a.io_cols) {
                     x.x *= a.scale; x.y *= a.scale;
                     if (a.rowvec) x = cmul(x, a.rowvec[rowo]);
-                    a.out[rowo * a.io_ld + col] = x;
+                    if constexpr (EPI == AZ_EPI_CROPOUT_PHI1) x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
+                    size_t drow = rowo + (size_t)a.io_shift_out;            // circular row shift of the destination (0 = none)
+                    if (drow >= (size_t)a.io_rows) drow -= (size_t)a.io_rows;
+                    if constexpr (EPI == AZ_EPI_CROPOUT_MAG) a.out_mag[drow * a.io_ld + col] = hypotf(x.x, x.y);
+                    else a.out[drow * a.io_ld + col] = x;
                 }
                 continue;
             } else if constexpr (EPI == AZ_EPI_TWCOL) {    // 32768-point line as 128 x 256: twiddle W_M^(+-col*m)
@@ -300,6 +308,8 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_PROCOL: return launch_az_one<R, W, true, AZ_EPI_PROCOL>(a, nq, st);
             case AZ_EPI_CROPOUT: return launch_az_one<R, W, true, AZ_EPI_CROPOUT>(a, nq, st);
             case AZ_EPI_SCALE_ROWSOUT: return launch_az_one<R, W, true, AZ_EPI_SCALE_ROWSOUT>(a, nq, st);
+            case AZ_EPI_CROPOUT_PHI1: return launch_az_one<R, W, true, AZ_EPI_CROPOUT_PHI1>(a, nq, st);
+            case AZ_EPI_CROPOUT_MAG: return launch_az_one<R, W, true, AZ_EPI_CROPOUT_MAG>(a, nq, st);
         }
     }
     return hipErrorInvalidValue;
@@ -323,6 +333,66 @@ hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int 
         case 64: return launch_az_r<64>(w, inv, epi, a, nq, st);
         case 128: return launch_az_r<128>(w, inv, epi, a, nq, st);
         case 256: return w == 32 ? launch_az_rw<256, 32>(inv, epi, a, nq, st) : hipErrorInvalidValue;   // 32768-row columns (general.hip)
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------
+// chirp-z middle step: FFT_R . filter spectrum . IFFT_R . conjugate twiddle on a [R rows x W cols] tile (see csa_kernels.h)
+// ------------------------------------------------------------------------------
+template <int R, int W>
+__global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_conv_kernel(AzArgs a) {
+    using PL = Plan<R>;
+    using EF = Edge<R, false>;
+    using EI = Edge<R, true>;
+    constexpr int P = PL::P;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    const int c = threadIdx.x % W;
+    const int t = threadIdx.x / W;
+    const int col = blockIdx.x * W + c;
+    const int q = blockIdx.y, ra = gridDim.y;
+    const size_t base = (size_t)q * R;
+    cf v[P];
+    constexpr int R0 = EF::R_first;
+#pragma unroll
+    for (int b = 0; b < P / R0; ++b)
+#pragma unroll
+        for (int r = 0; r < R0; ++r) v[b * R0 + r] = a.in[(base + EF::in_index(t, b, r)) * a.n_rg + col];
+    stockham_run<R, W, false, false>(v, t, c, lds, a.tw_r);
+    constexpr int RL = EF::R_last;             // == the reversed plan's first radix: the registers feed the inverse as they are
+    static_assert(EF::R_last == EI::R_first, "reversed plan starts with the forward plan's last radix");
+#pragma unroll
+    for (int b = 0; b < P / RL; ++b)
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const int k2 = EF::out_index(t, b, r);
+            v[b * RL + r] = cmul(v[b * RL + r], a.rowvec[q + ra * k2]);
+        }
+    if constexpr (PL::nstages > 1) __syncthreads();      // the forward's last gather is finished before the image is reused
+    stockham_run<R, W, true, true>(v, t, c, lds, a.tw_r);
+    constexpr int RLI = EI::R_last;
+#pragma unroll
+    for (int b = 0; b < P / RLI; ++b)
+#pragma unroll
+        for (int r = 0; r < RLI; ++r) {
+            const int m = EI::out_index(t, b, r);
+            const float rev = (float)(q * m) * a.tw_scale;          // exact: q m < M, 1/M a power of two
+            a.out[(base + m) * a.n_rg + col] = cmul(v[b * RLI + r], cis_frac(rev));
+        }
+}
+template <int R> static hipError_t launch_az_conv_r(int ra, const AzArgs& a, hipStream_t st) {
+    using CFG = AzCfg<R, 32>;
+    dim3 grid(a.n_rg / 32, ra);
+    hipLaunchKernelGGL((az_conv_kernel<R, 32>), grid, dim3(CFG::THREADS), CFG::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_az_conv(int s, int ra, const AzArgs& a, hipStream_t st) {
+    switch (s) {
+        case 16: return launch_az_conv_r<16>(ra, a, st);
+        case 32: return launch_az_conv_r<32>(ra, a, st);
+        case 64: return launch_az_conv_r<64>(ra, a, st);
+        case 128: return launch_az_conv_r<128>(ra, a, st);
     }
     return hipErrorInvalidValue;
 }

@@ -10,11 +10,15 @@
 namespace sarx {
 struct GeneralCsa;
 // csa_tables: also build the per-row range-convolution spectra the CSA path uses when n_rg is not a power of two
+// cus: compute units of the device (persistent range kernels size their grid from it)
 GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm, const float2* tw_all, std::string& err,
-                               bool csa_tables = true);
+                               bool csa_tables = true, int cus = 0);
 void general_csa_destroy(GeneralCsa* g);
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st);
 uint64_t general_csa_bytes(const GeneralCsa* g);
+// one range pass (RangeMode) on a dense [n_az x n_rg] image; hipErrorNotSupported unless the range extent has a direct
+// mixed-radix line kernel (range_mixed.hip)
+hipError_t general_csa_range_pass(GeneralCsa* g, int mode, const float2* in, float2* out, hipStream_t st);
 
 // building blocks shared with tdbp.hip
 // in-place line FFTs of `rows` contiguous lines of length m (power of two, 16..32768); the inverse carries 1/m.
@@ -32,7 +36,9 @@ hipError_t scale_copy_cols(const float2* in, int in_rows, int in_cols, size_t in
 struct Rda;
 Rda* rda_create(int n_ranges, int n_pulses, const sarx_radar_params* prm, const float2* tw_all, std::string& err);
 void rda_destroy(Rda* r);
-hipError_t rda_focus(Rda* r, const float2* d_in_pulse_major, hipStream_t st);
+// mag_out: device buffer for the [n_pulses x n_ranges] magnitude (nullptr: the object's own, see rda_mag);
+// want_rc: also keep the RCMC map (rda_stage(r, 2)); the other two intermediates are pipeline buffers and always valid
+hipError_t rda_focus(Rda* r, const float2* d_in_pulse_major, hipStream_t st, float* mag_out = nullptr, bool want_rc = true);
 const float* rda_mag(const Rda* r);                 // [n_pulses x n_ranges] = the reference's sar_image_mag.T
 const float2* rda_stage(const Rda* r, int which);   // 0 range-compressed, 1 range-Doppler, 2 after RCMC; [n_pulses x n_ranges]
 void rda_axes(const Rda* r, double* range_centered, double* cross_range, double* doppler);

@@ -137,6 +137,8 @@ struct GeneralCsa {
     cf *data = nullptr, *work_a = nullptr, *work_b = nullptr;
     size_t work_elems = 0;
     cf* ktab = nullptr;          // [n_az x rg.m]: spectrum of the range convolution kernel IFFT_N(Phi_2) per azimuth bin (see below)
+    bool rg_mixed = false;       // the range extent has a direct mixed-radix line kernel (range_mixed.hip): no chirp-z along range
+    int cus = 256;               // compute units of the device (persistent grids)
     uint64_t bytes = 0;
 };
 
@@ -175,8 +177,11 @@ static hipError_t rows_pow2(GeneralCsa* g, cf* buf, int rows, int m, bool inv, h
 // Optional fused ends of a two-step column transform (n > 128): the first step reads a smaller dense array (zero
 // outside it, times a per-row vector) instead of `in`; the last step of an inverse writes times a per-row vector and a
 // scale into a smaller dense array instead of `out`.  One HBM pass each instead of a separate copy.
-struct ColsSrc { const cf* p; size_t ld; int rows, cols; const cf* rowvec; };
-struct ColsDst { cf* p; size_t ld; int rows, cols; const cf* rowvec; float scale; };
+// shift: circular row shift while copying in (sequence element r = source row (r + shift) mod rows; rowvec is indexed by
+// r) / out (sequence element r -> destination row (r + shift) mod rows); mag: write |.| there (fp32, leading
+// dimension ld) instead of the complex value to p
+struct ColsSrc { const cf* p; size_t ld; int rows, cols; const cf* rowvec; int shift; };
+struct ColsDst { cf* p; size_t ld; int rows, cols; const cf* rowvec; float scale; int shift; float* mag; };
 static bool cols_two_step(int n) { return n > 128; }
 
 static hipError_t cols_pow2(GeneralCsa* g, const cf* in, cf* tmp, cf* out, int n, int ld, bool inv, hipStream_t st,
@@ -330,6 +335,37 @@ static hipError_t cols_core(GeneralCsa* g, cf* x, cf* y, bool inv, hipStream_t s
     GCK(cols_pow2(g, x, x, y, ax.m, g->ldc, false, st, inv ? ax.bhat_i : ax.bhat_f, src, nullptr, g->n_az));
     return cols_pow2(g, y, y, x, ax.m, g->ldc, true, st, nullptr, nullptr, dst, g->n_az);
 }
+// Chirp-z column transform of the dense [n_az x n_rg] array src into the dense array dst in THREE launches on one
+// [M x ldc] work array x (M = ra * s > 128):  (A) pre-chirp, zero padding and the first four-step stage while copying in,
+// (B) second stage . filter spectrum . first inverse stage in place (launch_az_conv), (C) last inverse stage, post-chirp,
+// scale and crop while copying out - optionally times Phi_1 (epi_last = AZ_EPI_CROPOUT_PHI1).  The padded rows are
+// never read in (A) nor written in (C).  Five launches and two work arrays before.
+static hipError_t cols_bluestein3(GeneralCsa* g, cf* x, bool inv, hipStream_t st, const ColsSrc& src, const ColsDst& dst,
+                                  int epi_last) {
+    const Axis& ax = g->az;
+    const int m = ax.m, ld = g->ldc;
+    int l2 = 0;
+    while ((1 << l2) < m) ++l2;
+    const int S = 1 << (l2 / 2), RA = m / S;
+    AzArgs a{};
+    a.n_rg = ld;
+    a.tw_n = m <= 16384 ? g->tw_all + m : nullptr;
+    a.c1 = g->c1; a.dt = 1.0 / g->p.sample_rate_hz; a.t_start = g->p.t_start_fast_s;
+    // (A) rows q + m S: FFT over m (length RA), twiddle W_M^(-q m'), same rows of x
+    a.in = src.p; a.out = x; a.tw_r = g->tw_all + RA; a.scale = 1.0f / (float)m;
+    a.io_ld = src.ld; a.io_rows = src.rows; a.io_cols = src.cols; a.rowvec = src.rowvec; a.io_shift_in = src.shift;
+    a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
+    GCK(launch_az_tile(RA, 32, false, AZ_EPI_TWIDDLE_PADIN, a, S, st));
+    // (B) rows q S + m in place
+    a.in = x; a.out = x; a.tw_r = g->tw_all + S; a.rowvec = inv ? ax.bhat_i : ax.bhat_f; a.tw_scale = 1.0f / (float)m;
+    GCK(launch_az_conv(S, RA, a, st));
+    // (C) rows q + m' S: inverse FFT over m' (length RA) -> sequence index q + S m, cropped into dst
+    a.in = x; a.out = dst.p; a.tw_r = g->tw_all + RA; a.rowvec = dst.rowvec; a.scale = dst.scale / (float)m;
+    a.io_ld = dst.ld; a.io_rows = dst.rows; a.io_cols = dst.cols; a.io_shift_in = 0; a.io_shift_out = dst.shift; a.out_mag = dst.mag;
+    a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
+    return launch_az_tile(RA, 32, true, dst.mag ? AZ_EPI_CROPOUT_MAG : epi_last, a, S, st);
+}
+
 // line transform in place on w [n_az x m_rg] (chirped and padded when the axis is not direct)
 static hipError_t rows_core(GeneralCsa* g, cf* w, bool inv, hipStream_t st) {
     const Axis& ax = g->rg;
@@ -371,12 +407,58 @@ static hipError_t build_range_kernel_table(GeneralCsa* g, hipStream_t st) {
     return hipStreamSynchronize(st);
 }
 
+// one range pass of the plan's geometry on a dense [n_az x n_rg] image (direct mixed-radix line lengths only)
+hipError_t general_csa_range_pass(GeneralCsa* g, int mode, const float2* in, float2* out, hipStream_t st) {
+    if (!g->rg_mixed) return hipErrorNotSupported;
+    RangeArgs a{};
+    a.in = in; a.out = out; a.c2 = g->c2; a.c3 = g->c3;
+    a.dt = 1.0 / g->p.sample_rate_hz; a.df = 1.0 / ((double)g->n_rg * a.dt);
+    a.t_start = g->p.t_start_fast_s; a.t0 = 2.0 * g->p.range_ref_m / 299792458.0;
+    a.inv_n = 1.0f / (float)g->n_rg; a.n_az = g->n_az;
+    return launch_range_mixed(g->n_rg, mode, a, g->cus, st);
+}
+
 // sar_focus_csa (:233-385) at any size.  Buffers: wa/wb [m_az x ldc] for the column transforms, work_a doubles as
 // the [n_az x m_rg] line-transform array when the range axis is not a power of two (else the dense image `data`).
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st) {
     const Axis &az = g->az, &rg = g->rg;
     const int n_az = g->n_az, n_rg = g->n_rg, ld = g->ldc;
     cf *wa = g->work_a, *wb = g->work_b;
+    if (g->rg_mixed) {
+        // the range extent has a direct line kernel (13200): no chirp-z along range, one fused launch for :278-382
+        const bool z3 = !az.direct && cols_two_step(az.m);
+        if (z3) {                     // azimuth FFT (:233) as a three-launch chirp-z with Phi_1 (:272-274) in its last epilogue
+            const ColsSrc src{d_in, (size_t)n_rg, n_az, n_rg, az.chirp_f};
+            const ColsDst dst{g->data, (size_t)n_rg, n_az, n_rg, az.chirp_f, 1.0f};
+            GCK(cols_bluestein3(g, wa, false, st, src, dst, AZ_EPI_CROPOUT_PHI1));
+        } else {
+            cf *first = az.direct ? wa : wb, *other = az.direct ? wb : wa, *res = nullptr;
+            if (cols_two_step(az.m)) {
+                const ColsSrc src{d_in, (size_t)n_rg, n_az, n_rg, az.direct ? nullptr : az.chirp_f};
+                GCK(cols_core(g, first, other, false, st, &res, &src));
+            } else {
+                GCK(scale_copy(d_in, n_az, n_rg, n_rg, first, az.m, ld, ld, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
+                GCK(cols_core(g, first, other, false, st, &res));
+            }
+            GCK(bridge<1>(g, res, ld, g->data, n_rg, n_az, n_rg, az.direct ? nullptr : az.chirp_f, nullptr, 1.0f, st));
+        }
+        GCK(general_csa_range_pass(g, RG_FUSED, g->data, g->data, st));   // range FFT . Phi_2 . IFFT . Phi_3 in place on the dense image
+        if (z3) {                     // azimuth IFFT (:385)
+            const ColsSrc src{g->data, (size_t)n_rg, n_az, n_rg, az.chirp_i};
+            const ColsDst dst{d_out, (size_t)n_rg, n_az, n_rg, az.chirp_i, 1.0f / (float)n_az};
+            return cols_bluestein3(g, wa, true, st, src, dst, AZ_EPI_CROPOUT);
+        }
+        cf* res = nullptr;
+        GCK(scale_copy(g->data, n_az, n_rg, n_rg, wb, cols_two_step(az.m) ? n_az : az.m, ld, ld, az.direct ? nullptr : az.chirp_i,
+                       nullptr, 1.0f, st));
+        if (cols_two_step(az.m)) {
+            const ColsDst dst{d_out, (size_t)n_rg, n_az, n_rg, az.direct ? nullptr : az.chirp_i, az.direct ? 1.0f : 1.0f / (float)n_az};
+            return cols_core(g, wb, wa, true, st, &res, nullptr, &dst);
+        }
+        GCK(cols_core(g, wb, wa, true, st, &res));
+        return scale_copy(res, n_az, n_rg, ld, d_out, n_az, n_rg, n_rg, nullptr, nullptr, az.direct ? 1.0f : 1.0f / (float)n_az, st, 0,
+                          az.direct ? nullptr : az.chirp_i);
+    }
     cf* lines = rg.direct ? g->data : g->work_a;            // where the range transforms run
     const size_t lines_ld = rg.direct ? (size_t)n_rg : (size_t)rg.m;
     const int lines_cols = rg.direct ? n_rg : rg.m;
@@ -484,6 +566,43 @@ __global__ __launch_bounds__(256) void rda_azcomp_kernel(RdaArgsDev a) {
         a.out[i] = cmul(a.in[i], cis_rev(g * a.fd[k] * a.fd[k]));
     }
 }
+// RCMC (:411-427) and azimuth compression (:431-435) in one pass over the range-Doppler map: the migrated sample is
+// interpolated (rda_rcmc_kernel's arithmetic), stored to the RCMC map only when the caller asked for that
+// intermediate, multiplied by the compression phase and stored once.  One HBM round trip instead of two.
+__global__ __launch_bounds__(256) void rda_rcmc_azcomp_kernel(RdaArgsDev a, cf* rc_out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.n_r) return;
+    const double r0 = a.r_axis[0], rj = a.r_axis[j];
+    const double dr = (a.n_r > 1) ? (a.r_axis[a.n_r - 1] - r0) / (double)(a.n_r - 1) : 1.0;
+    const double g = -0.5 * a.k_ac * rj;
+    for (int k = blockIdx.y; k < a.n_p; k += gridDim.y) {
+        const double fd2 = a.fd[k] * a.fd[k];
+        const double alpha = fd2 * a.k_rcmc;
+        const cf* row = a.in + (size_t)k * a.n_r;
+        cf y = make_float2(0.f, 0.f);
+        if (a.n_r == 1) {
+            y = row[0];
+        } else {
+            const double s = 1.0 - alpha;
+            const double x_first = r0 * s, x_last = a.r_axis[a.n_r - 1] * s;
+            if (rj >= x_first && rj <= x_last) {
+                double u = (rj / s - r0) / dr;
+                int j0 = (int)floor(u);
+                if (j0 < 0) j0 = 0;
+                if (j0 > a.n_r - 2) j0 = a.n_r - 2;
+                while (j0 > 0 && a.r_axis[j0] * s > rj) --j0;
+                while (j0 < a.n_r - 2 && a.r_axis[j0 + 1] * s <= rj) ++j0;
+                const double xa = a.r_axis[j0] * s, xb = a.r_axis[j0 + 1] * s;
+                const float f = (float)((rj - xa) / (xb - xa));
+                const cf p = row[j0], q = row[j0 + 1];
+                y = make_float2(fmaf(f, q.x - p.x, p.x), fmaf(f, q.y - p.y, p.y));
+            }
+        }
+        const size_t i = (size_t)k * a.n_r + j;
+        if (rc_out) rc_out[i] = y;
+        a.out[i] = cmul(y, cis_rev(g * fd2));
+    }
+}
 __global__ __launch_bounds__(256) void rda_mag_kernel(const cf* in, float* mag, size_t n) {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) mag[i] = hypotf(in[i].x, in[i].y);
@@ -493,6 +612,7 @@ struct Rda {
     GeneralCsa* g = nullptr;      // buffers, azimuth axis (n_az = pulses, n_rg = ranges)
     int n_p = 0, n_r = 0, m_c = 0, l_mf = 0;
     cf *hhat = nullptr, *win = nullptr;        // filter spectrum [m_c] (split order at 32768), azimuth window [n_p]
+    cf* pre_f = nullptr;                       // chirp-z azimuth: pre-chirp[r] * window[(r + shift) mod n_p], per sequence index r
     double *fd = nullptr, *r_axis = nullptr;
     cf *pc = nullptr, *rd = nullptr, *rc = nullptr;   // the three intermediates the reference returns
     float* mag = nullptr;
@@ -504,7 +624,7 @@ struct Rda {
 void rda_destroy(Rda* r) {
     if (!r) return;
     general_csa_destroy(r->g);
-    hipFree(r->hhat); hipFree(r->win); hipFree(r->fd); hipFree(r->r_axis);
+    hipFree(r->hhat); hipFree(r->win); hipFree(r->pre_f); hipFree(r->fd); hipFree(r->r_axis);
     hipFree(r->pc); hipFree(r->rd); hipFree(r->rc); hipFree(r->mag);
     delete r;
 }
@@ -554,6 +674,17 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     std::vector<zd> win(n_p);
     for (int i = 0; i < n_p; ++i) win[i] = zd(n_p > 1 ? 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(n_p - 1)) : 1.0, 0.0);
     if ((e = upload(win, &r->win)) != hipSuccess) return bail("upload window", e);
+    if (!r->g->az.direct && cols_two_step(r->g->az.m)) {
+        // three-launch chirp-z along pulses: window and fftshift are folded into the copy-in; sequence element e is
+        // source row (e + sh) mod n_p (the roll by n_p/2 of :396-399), so it carries chirp[e] * window[(e + sh) mod n_p]
+        const int sh = (n_p - n_p / 2) % n_p;
+        std::vector<zd> pre(n_p);
+        for (int k = 0; k < n_p; ++k) {
+            const long long k2 = ((long long)k * k) % (2LL * n_p);
+            pre[k] = std::polar(1.0, -M_PI * (double)k2 / (double)n_p) * win[(k + sh) % n_p];
+        }
+        if ((e = upload(pre, &r->pre_f)) != hipSuccess) return bail("upload window", e);
+    }
     // axes (:363-373, :402-407)
     r->h_fd.resize(n_p); r->h_r.resize(n_r);
     const double t_grp = 2.0 * prm->range_ref_m / 299792458.0;
@@ -579,8 +710,9 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
 }
 
 // d_in: [n_p x n_r] complex64 (the reference's phist transposed).  Results stay in the object's buffers.
-hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st) {
+hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out, bool want_rc) {
     GeneralCsa* g = r->g;
+    if (!mag_out) mag_out = r->mag;
     const int n_p = r->n_p, n_r = r->n_r, m = r->m_c;
     cf* w = g->work_a;
     // 1 range compression
@@ -592,22 +724,31 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st) {
     GCK(scale_copy(w + (r->l_mf - 1) / 2, n_p, n_r, m, r->pc, n_p, n_r, n_r, nullptr, nullptr, 1.0f, st));   // mode='same'
     // 2 window, fftshift . FFT . fftshift over pulses: roll by h = n_p/2 is source row (r - h) mod n
     const int h = n_p / 2, sh = (n_p - h) % n_p;
-    GCK(fft_cols(g, r->pc, r->rd, false, st, sh, r->win, sh));
-    // 3, 4
+    const bool z3 = r->pre_f != nullptr;           // chirp-z along pulses in three launches, shifts / window / magnitude in its ends
+    if (z3) {
+        const ColsSrc src{r->pc, (size_t)n_r, n_p, n_r, r->pre_f, sh};
+        const ColsDst dst{r->rd, (size_t)n_r, n_p, n_r, g->az.chirp_f, 1.0f, (n_p - sh) % n_p, nullptr};
+        GCK(cols_bluestein3(g, g->work_a, false, st, src, dst, AZ_EPI_CROPOUT));
+    } else {
+        GCK(fft_cols(g, r->pc, r->rd, false, st, sh, r->win, sh));
+    }
+    // 3, 4: RCMC and azimuth compression in one pass (the RCMC map is stored only on request)
     RdaArgsDev a{};
     a.fd = r->fd; a.r_axis = r->r_axis; a.n_p = n_p; a.n_r = n_r;
     a.k_rcmc = r->lam * r->lam / (8.0 * r->vr * r->vr);
     a.k_ac = r->lam / (2.0 * r->vr * r->vr);
     dim3 grid((n_r + 255) / 256, n_p < 16384 ? n_p : 16384);
-    a.in = r->rd; a.out = r->rc;
-    hipLaunchKernelGGL(rda_rcmc_kernel, grid, dim3(256), 0, st, a);
-    GCK(hipGetLastError());
-    a.in = r->rc; a.out = g->data;
-    hipLaunchKernelGGL(rda_azcomp_kernel, grid, dim3(256), 0, st, a);
+    a.in = r->rd; a.out = g->data;
+    hipLaunchKernelGGL(rda_rcmc_azcomp_kernel, grid, dim3(256), 0, st, a, want_rc ? r->rc : (cf*)nullptr);
     GCK(hipGetLastError());
     // 5 ifftshift . IFFT . ifftshift: source row (r + h) mod n both ways; magnitude
+    if (z3) {
+        const ColsSrc src{g->data, (size_t)n_r, n_p, n_r, g->az.chirp_i, h};
+        const ColsDst dst{nullptr, (size_t)n_r, n_p, n_r, g->az.chirp_i, 1.0f / (float)n_p, (n_p - h) % n_p, mag_out};
+        return cols_bluestein3(g, g->work_a, true, st, src, dst, AZ_EPI_CROPOUT_MAG);
+    }
     GCK(fft_cols(g, g->data, g->data, true, st, h, nullptr, h));
-    hipLaunchKernelGGL(rda_mag_kernel, dim3(4096), dim3(256), 0, st, g->data, r->mag, (size_t)n_p * n_r);
+    hipLaunchKernelGGL(rda_mag_kernel, dim3(4096), dim3(256), 0, st, g->data, mag_out, (size_t)n_p * n_r);
     return hipGetLastError();
 }
 
@@ -635,11 +776,14 @@ void general_csa_destroy(GeneralCsa* g) {
 }
 
 GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm, const float2* tw_all, std::string& err,
-                               bool csa_tables) {
+                               bool csa_tables, int cus) {
     if (n_az < 2 || n_rg < 2 || n_rg > 32768 || n_az > 32768) { err = "sizes must be in [2, 32768]"; return nullptr; }
     GeneralCsa* g = new GeneralCsa();
     g->n_az = n_az; g->n_rg = n_rg; g->p = *prm; g->tw_all = tw_all;
     g->ldc = (n_rg + 31) / 32 * 32;
+    if (cus > 0) g->cus = cus;
+    const char* mv = getenv("SARX_RANGE_MIXED");          // SARX_RANGE_MIXED=0 keeps the chirp-z range path (A/B measurements)
+    g->rg_mixed = csa_tables && range_mixed_supported(n_rg) && !(mv && atoi(mv) == 0);
     auto bail = [&](const char* what, hipError_t e) {
         err = std::string(what) + ": " + hipGetErrorString(e);
         general_csa_destroy(g);
@@ -650,7 +794,8 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
         if (e == hipErrorInvalidValue) { err = "a non-power-of-two n_az must be <= 16384 (chirp-z length 32768)"; general_csa_destroy(g); return nullptr; }
         return bail("azimuth tables", e);
     }
-    if ((e = axis_init(g->rg, n_rg, 65536, 16384, true)) != hipSuccess) return bail("range tables", e);
+    if (g->rg_mixed) { g->rg.n = n_rg; g->rg.m = n_rg; g->rg.direct = true; }     // no chirp-z tables along range
+    else if ((e = axis_init(g->rg, n_rg, 65536, 16384, true)) != hipSuccess) return bail("range tables", e);
     // migration factors in natural fftfreq order, any parity (sar_ati_dcpa_sim_csa.py:225,244-249,262)
     const double C0 = 299792458.0, lam = prm->wavelength_m, Kr = prm->chirp_rate_hz_s, Vr = prm->platform_speed_mps,
                  Rref = prm->range_ref_m, fa_step = 1.0 / ((double)n_az * (1.0 / prm->prf_hz));

@@ -48,6 +48,16 @@ __device__ __forceinline__ FixPhase phi3_seed(int j0, int step, double2 c3, doub
     const double d0 = tau - t0, h = (double)step * dt;
     return make_fix(fma(c3.x, tau, c3.y * d0 * d0), h * fma(c3.y, 2.0 * d0 + h, c3.x), 2.0 * c3.y * h * h);
 }
+// direct forms (one fp64 evaluation per sample): any line length, no progression needed
+__device__ __forceinline__ cf phi2_at(int ks, double2 c2, double df) {
+    const double f = (double)ks * df;
+    return cis_rev(f * fma(c2.x, f, c2.y));
+}
+__device__ __forceinline__ cf phi3_at(int j, double2 c3, double dt, double t_start, double t0) {
+    const double tau = __dadd_rn(t_start, __dmul_rn((double)j, dt));   // :219, unfused like NumPy
+    const double d = tau - t0;
+    return cis_rev(fma(c3.x, tau, c3.y * d * d));
+}
 // Phi_1[i,j] = exp(-j pi Kr Cs_i (tau_j - tau_ref_i)^2)                           (:262-272)
 //   c1[i] = { -0.5 Kr Cs_i, tau_ref_i }.  In the azimuth tile a thread's samples
 // share j and differ in i, so this one is evaluated directly.

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
 #pragma unroll
         for (int q = 2; q < 16; ++q) cw[b][q] = cmul(cw[b][q / 2], cw[b][q - q / 2]);
     }
-    for (int row = blockIdx.x; row < a.n_az; row += gridDim.x) {
+    for (int line = blockIdx.x; line < a.n_az; line += gridDim.x) {
+        const int row = range_row(a, line);
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));                   // keep addresses per-line (no hoisting out of the loop + spilling)
         const int w = t >> 6, l = t & 63;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
         }
         cf* img = lds + (2 * w + (l >> 5)) * ROWSTR;  // the half wave's private image
         const int li = l & 31;
-        cross_fwd32(v, t, w, l, lds, row != (int)blockIdx.x);
+        cross_fwd32(v, t, w, l, lds, line != (int)blockIdx.x);
         sub1024_r32<false>(v, li, img, wp);
         // Phi_2: v[r] is bin k = (2w+h) + 16 i + 512 r; r >= 16 are the negative frequencies
         {

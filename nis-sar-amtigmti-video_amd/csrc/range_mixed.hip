@@ -1,0 +1,218 @@
+// Range pass for line lengths that are not powers of two: direct mixed-radix transforms, no chirp-z.
+//
+// The reference's native scene has 13200 samples per pulse (sar_ati_dcpa_sim_csa.py:111: int(22e-6 * 600e6)).
+// 13200 = 24 * 22 * 25 = (3*8) * (2*11) * (5*5): three Stockham stages whose butterflies are in-register DFTs of length
+// 24, 22 and 25 (fft_mixed.hpp), the line exchanged through one LDS image between stages.  One workgroup per line,
+// persistent over lines; a stage of radix R has N/R butterflies (550, 600, 528), one per thread of a 640-thread
+// workgroup.  The fused mode runs  FFT . Phi_2 . IFFT . Phi_3  (:278-382) in one launch: the inverse uses the radices
+// in reverse order, so its first butterfly consumes exactly the registers the forward's last butterfly produced
+// (bins t + r N/25) and the spectrum never leaves them.  One HBM round trip of the unpadded line instead of the
+// five padded ones of the chirp-z route (32768-point convolution).
+//
+// Phases: fp64-seeded fixed-point accumulators along each thread's arithmetic progression of bins / samples
+// (phase.hpp); the one bin per thread where the fftfreq sign change falls inside a progression is evaluated directly.
+#include "csa_kernels.h"
+#include "fft_mixed.hpp"
+#include "phase.hpp"
+
+namespace sarx {
+
+// Exchange layouts.  A direction runs radices (RA, RB, RC); between its stages the line crosses LDS twice, and each crossing
+// has its own 2-D layout chosen so that BOTH sides address it as  per-thread base + compile-time constant * r  (no
+// address arithmetic per access; LDS instructions carry the constants as immediate offsets):
+//   crossing 1 (after the NS = 1 stage): element w = RA j + r is stored at  r * PITCH + j          (RA rows of N/RA)
+//       the next stage reads index j' + r' RA RC, i.e. row j' mod RA, column j' div RA + RC r'
+//   crossing 2 (after the NS = RA stage): element w = (j div RA) RA RB + (j mod RA) + RA r lives in block j div RA of
+//       N/RC = RA RB elements:  (j div RA) * PITCH + (j mod RA) + RA r;   the last stage reads  j' + r' * PITCH
+// The pitches carry a few pad elements (picked with a bank-conflict count of every access: worst case 1.9x the
+// conflict-free LDS cycles on the strided reads of crossing 1, about 3 us of LDS time per 13200-sample line in all).
+template <int N_, int R1_, int R2_, int R3_, int T_, int P1_, int P2_, int P3_, int P4_> struct MixCfg {
+    static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_, T = T_;
+    static_assert(R1 * R2 * R3 == N, "radices must multiply to the line length");
+    static_assert(N / R1 <= T && N / R2 <= T && N / R3 <= T, "one butterfly per thread and stage");
+    static constexpr int RMAX = (R1 > R2 ? (R1 > R3 ? R1 : R3) : (R2 > R3 ? R2 : R3));
+    static constexpr int G1 = N / R1, G2 = N / R2, G3 = N / R3;
+    // forward crossings 1, 2 and inverse crossings 1, 2
+    static constexpr int PITCH_F1 = G1 + P1_, PITCH_F2 = G3 + P2_, PITCH_I1 = G3 + P3_, PITCH_I2 = G1 + P4_;
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int LDS_ELEMS = cmax(cmax(R1 * PITCH_F1, R3 * PITCH_F2), cmax(R3 * PITCH_I1, R1 * PITCH_I2));
+    static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * sizeof(cf);
+};
+
+template <int RA, int PITCH> __device__ __forceinline__ void cross1_write(const cf* v, int j, cf* lds) {
+    cf* p = lds + j;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) p[r * PITCH] = v[r];
+}
+template <int RA, int RB, int RC, int PITCH> __device__ __forceinline__ void cross1_read(cf* v, int j, const cf* lds) {
+    const cf* p = lds + (j % RA) * PITCH + (j / RA);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) v[r] = p[RC * r];
+}
+template <int RA, int RB, int PITCH> __device__ __forceinline__ void cross2_write(const cf* v, int j, cf* lds) {
+    cf* p = lds + (j / RA) * PITCH + (j % RA);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) p[RA * r] = v[r];
+}
+template <int RC, int PITCH> __device__ __forceinline__ void cross2_read(cf* v, int j, const cf* lds) {
+    const cf* p = lds + j;
+#pragma unroll
+    for (int r = 0; r < RC; ++r) v[r] = p[r * PITCH];
+}
+// butterfly j of a stage with radix R after NS = product of earlier radices: twiddle exp(-+ 2 pi i (j mod NS) r / (NS R))
+template <int R, int NS, bool INV> __device__ __forceinline__ void mix_twiddle(cf* v, int j) {
+    if constexpr (NS > 1) {
+        // the argument (< 1/R revolutions) carries 1.2e-7 relative rounding, so even the highest power w^(R-1) is off by
+        // less than 1.2e-7 revolutions
+        const float x = (float)(j % NS) * (1.0f / (float)(NS * R));
+        mix::apply_powers<R>(v, cis_frac(INV ? x : -x));
+    }
+}
+
+template <class C, int MODE>
+__global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
+    constexpr int N = C::N, R1 = C::R1, R2 = C::R2, R3 = C::R3, G1 = C::G1, G2 = C::G2, G3 = C::G3;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    constexpr bool FWD = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED);
+    constexpr bool BWD = (MODE == RG_IFFT || MODE == RG_IFFT_PHI3 || MODE == RG_FUSED);
+    // Phi_2 along a thread's bins k = t + r G3: non-negative frequencies for r <= R_LO and negative ones for r >= R_HI
+    // whatever t is; in between (at most one r) it depends on the thread.  Each run is one fp64-seeded fixed-point phase
+    // accumulator (phase.hpp), the in-between bins are evaluated directly.
+    constexpr int HALF = (N + 1) / 2;
+    constexpr int R_LO = (HALF - G3) / G3, R_HI = (HALF + G3 - 1) / G3;
+    for (int line = blockIdx.x; line < a.n_az; line += gridDim.x) {
+        const int row = range_row(a, line);
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));                     // per-line addresses: nothing hoisted out of the line loop and spilled
+        const cf* __restrict__ src = a.in + (size_t)row * N;
+        cf* __restrict__ dst = a.out + (size_t)row * N;
+        cf v[C::RMAX];
+        if (line != (int)blockIdx.x) __syncthreads();   // the previous line's last reads of the image are finished
+        if constexpr (FWD) {
+            // stage 1: radix R1, NS = 1, straight from HBM (8 bytes per lane, consecutive lanes consecutive samples)
+            if (t < G1) {
+#pragma unroll
+                for (int r = 0; r < R1; ++r) v[r] = src[t + r * G1];
+                mix::dft_any<R1, false>(v);
+                cross1_write<R1, C::PITCH_F1>(v, t, lds);
+            }
+            __syncthreads();
+            // stage 2: radix R2, NS = R1
+            if (t < G2) {
+                cross1_read<R1, R2, R3, C::PITCH_F1>(v, t, lds);
+                mix_twiddle<R2, R1, false>(v, t);
+                mix::dft_any<R2, false>(v);
+            }
+            __syncthreads();
+            if (t < G2) cross2_write<R1, R2, C::PITCH_F2>(v, t, lds);
+            __syncthreads();
+            // stage 3: radix R3, NS = R1 R2; thread t ends with bins k = t + r G3
+            if (t < G3) {
+                cross2_read<R3, C::PITCH_F2>(v, t, lds);
+                mix_twiddle<R3, R1 * R2, false>(v, t);
+                mix::dft_any<R3, false>(v);
+                if constexpr (MODE == RG_FFT) {
+                    if (a.mulvec) {
+                        const cf* __restrict__ mv = a.mulvec + (size_t)(row % a.mul_period) * N;
+#pragma unroll
+                        for (int r = 0; r < R3; ++r) dst[t + r * G3] = cmul(v[r], mv[t + r * G3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R3; ++r) dst[t + r * G3] = v[r];
+                    }
+                } else {
+                    const double2 c2 = a.c2[row];
+                    FixPhase lo = phi2_seed(t, G3, c2, a.df);                        // numpy.fft.fftfreq order: k, then k - N
+                    FixPhase hi = phi2_seed(t + R_HI * G3 - N, G3, c2, a.df);
+#pragma unroll
+                    for (int r = 0; r < R3; ++r) {
+                        const int k = t + r * G3;
+                        cf ph;
+                        if (r <= R_LO) ph = lo.next();
+                        else if (r >= R_HI) ph = hi.next();
+                        else ph = phi2_at(k < HALF ? k : k - N, c2, a.df);
+                        v[r] = cmul(v[r], ph);
+                        if constexpr (MODE == RG_FFT_PHI2) dst[k] = v[r];
+                    }
+                }
+            }
+        }
+        if constexpr (BWD) {
+            // inverse, radices reversed: stage 1 radix R3 on samples t + r G3 - in the fused mode the registers as they are
+            if (t < G3) {
+                if constexpr (!FWD) {
+#pragma unroll
+                    for (int r = 0; r < R3; ++r) v[r] = src[t + r * G3];
+                }
+                mix::dft_any<R3, true>(v);
+            }
+            if constexpr (FWD) __syncthreads();         // forward stage 3's reads of the image are finished
+            if (t < G3) cross1_write<R3, C::PITCH_I1>(v, t, lds);
+            __syncthreads();
+            // stage 2: radix R2, NS = R3
+            if (t < G2) {
+                cross1_read<R3, R2, R1, C::PITCH_I1>(v, t, lds);
+                mix_twiddle<R2, R3, true>(v, t);
+                mix::dft_any<R2, true>(v);
+            }
+            __syncthreads();
+            if (t < G2) cross2_write<R3, R2, C::PITCH_I2>(v, t, lds);
+            __syncthreads();
+            // stage 3: radix R1, NS = R3 R2; thread t ends with samples n = t + r G1
+            if (t < G1) {
+                cross2_read<R1, C::PITCH_I2>(v, t, lds);
+                mix_twiddle<R1, R3 * R2, true>(v, t);
+                mix::dft_any<R1, true>(v);
+                const float s = a.inv_n;
+                if constexpr (MODE == RG_IFFT) {
+#pragma unroll
+                    for (int r = 0; r < R1; ++r) dst[t + r * G1] = make_float2(v[r].x * s, v[r].y * s);
+                } else {
+                    const double2 c3 = a.c3[row];
+                    FixPhase q = phi3_seed(t, G1, c3, a.dt, a.t_start, a.t0);
+#pragma unroll
+                    for (int r = 0; r < R1; ++r) {
+                        cf ph = q.next();
+                        ph.x *= s; ph.y *= s;
+                        dst[t + r * G1] = cmul(v[r], ph);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- supported lengths ----------------------------------------------------------------------------------------------
+using Mix13200 = MixCfg<13200, 24, 22, 25, 640, 0, 8, 1, 3>;   // pads from the bank-conflict count of tools/lds_layout_sim.py
+
+template <class C, int MODE> static hipError_t launch_mixed(const RangeArgs& a, int cus, hipStream_t st) {
+    auto k = range_mixed_kernel<C, MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int per_cu = (int)((160 * 1024) / C::LDS_BYTES) < 1 ? 1 : (int)((160 * 1024) / C::LDS_BYTES);
+    const int grid = persistent_grid(per_cu, cus, a.n_az);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::T), C::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+template <class C> static hipError_t launch_mixed_mode(int mode, const RangeArgs& a, int cus, hipStream_t st) {
+    switch (mode) {
+        case RG_FFT: return launch_mixed<C, RG_FFT>(a, cus, st);
+        case RG_IFFT: return launch_mixed<C, RG_IFFT>(a, cus, st);
+        case RG_FFT_PHI2: return launch_mixed<C, RG_FFT_PHI2>(a, cus, st);
+        case RG_IFFT_PHI3: return launch_mixed<C, RG_IFFT_PHI3>(a, cus, st);
+        case RG_FUSED: return launch_mixed<C, RG_FUSED>(a, cus, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+bool range_mixed_supported(int n_rg) { return n_rg == 13200; }
+
+hipError_t launch_range_mixed(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st) {
+    switch (n_rg) {
+        case 13200: return launch_mixed_mode<Mix13200>(mode, a, cus, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace sarx

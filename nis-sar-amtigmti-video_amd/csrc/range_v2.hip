@@ -217,9 +217,10 @@ __global__ __launch_bounds__(V2<N>::THREADS, 4) void range_pass_v2_kernel(RangeA
     float* my_lds = lds + r_in_wg * CFG::LDS_PER_ROW;
     const int groups = (a.n_az + CFG::ROWS - 1) / CFG::ROWS;
     for (int g = blockIdx.x; g < groups; g += gridDim.x) {
-        int row = g * CFG::ROWS + r_in_wg;
-        const bool live = row < a.n_az;
-        if (!live) row = a.n_az - 1;               // keep barriers uniform
+        int line = g * CFG::ROWS + r_in_wg;
+        const bool live = line < a.n_az;
+        if (!live) line = a.n_az - 1;              // keep barriers uniform
+        const int row = range_row(a, line);
         // make the lane's index opaque per line: otherwise every LDS/global address of the body is
         // loop-invariant, gets hoisted out of this loop and spills (192 B/lane of scratch measured)
         int tt = t;

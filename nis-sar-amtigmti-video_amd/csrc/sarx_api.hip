@@ -108,6 +108,7 @@ struct sarx_plan {
     sarx_radar_params p{};
     int az_s = 0;          // four-step split: n_az = (n_az/az_s) * az_s; az_s == n_az means single step
     int az_w = 32;         // azimuth tile width (range samples)
+    int slab_tiles = 0;    // > 0: slab mode of sarx_csa_focus_dev with this many azimuth tiles per group (SARX_SLAB_MIB)
     double2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr;
     float2* buf_b = nullptr;           // scratch image
     float2* buf_a = nullptr;           // second scratch (RG_MAJOR only)
@@ -303,7 +304,7 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
     p->ctx = c; p->n_az = n_az; p->n_rg = n_rg; p->flags = flags; p->p = *prm;
     if (general) {       // any other size: chirp-z transforms over the power-of-two kernels (general.hip)
         std::string err;
-        p->gen = general_csa_create(n_az, n_rg, prm, c->tw_all, err);
+        p->gen = general_csa_create(n_az, n_rg, prm, c->tw_all, err, true, c->cus);
         if (!p->gen) { delete p; return fail(c, SARX_ERR_UNSUPPORTED, "n_az=%d n_rg=%d: %s", n_az, n_rg, err.c_str()); }
         p->bytes = general_csa_bytes(p->gen);
         if (flags & SARX_OUT_RG_MAJOR) {
@@ -316,6 +317,16 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
     }
     p->az_s = (n_az <= 128) ? n_az : (1 << (ilog2(n_az) / 2));
     p->az_w = (n_rg % 32 == 0) ? 32 : 16;
+    if (const char* e = getenv("SARX_SLAB_MIB")) {     // rows of one group of tiles, in MiB (0 = off)
+        const double mib = atof(e);
+        const double tile_mib = (double)p->az_s * n_rg * sizeof(float2) / (1024.0 * 1024.0);
+        if (mib > 0 && p->az_s != n_az) {
+            int q = (int)(mib / tile_mib);
+            if (q < 1) q = 1;
+            if (q > n_az / p->az_s) q = n_az / p->az_s;
+            p->slab_tiles = q;
+        }
+    }
     if (const char* e = getenv("SARX_AZ_W")) { const int w = atoi(e); if ((w == 16 || w == 32 || w == 64) && n_rg % w == 0) p->az_w = w; }
 
     // migration factors, natural fftfreq order (sar_ati_dcpa_sim_csa.py:225,244-249,262)
@@ -424,10 +435,12 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
     return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->cus, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
 }
 
-// azimuth FFT (+epilogue) in -> out via tmp (tmp unused for single-step sizes); in is not modified
-static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out) {
+// One step of the two-step (four-step) azimuth transform n_az = RA * S over the tiles [q0, q0 + nq):
+//   step A: tile q in [0,S):  rows q + m*S, (I)FFT over m (length RA), twiddle W_n^(-+q*m'), same rows of `out`
+//   step B: tile q in [0,RA): rows q*S + m, (I)FFT over m (length S), rows q + m'*RA of `out` (natural bin order), epilogue
+static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, void* out, int q0, int nq) {
     sarx_ctx* c = p->ctx;
-    const int n = p->n_az, S = p->az_s, RA = n / S;
+    const int n = p->n_az, RA = n / S;
     AzArgs a{};
     a.tw_n = c->tw_all + n;
     a.c1 = p->c1;
@@ -435,25 +448,41 @@ static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out)
     a.t_start = p->p.t_start_fast_s;
     a.scale = 1.0f / (float)n;
     a.n_rg = p->n_rg;
-    const int epi_last = inv ? AZ_EPI_SCALE : AZ_EPI_PHI1;
+    a.in = (const float2*)in; a.out = (float2*)out;
+    a.q0 = q0;
+    if (!step_b) {
+        a.tw_r = c->tw_all + RA;
+        a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
+        HIPCHK(c, launch_az_tile(RA, p->az_w, inv, AZ_EPI_TWIDDLE, a, nq, c->stream));
+    } else {
+        a.tw_r = c->tw_all + S;
+        a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
+        HIPCHK(c, launch_az_tile(S, p->az_w, inv, inv ? AZ_EPI_SCALE : AZ_EPI_PHI1, a, nq, c->stream));
+    }
+    return SARX_OK;
+}
+
+// azimuth FFT (+epilogue) in -> out via tmp (tmp unused for single-step sizes); in is not modified
+static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out) {
+    sarx_ctx* c = p->ctx;
+    const int n = p->n_az, S = p->az_s;
     if (S == n) {          // one tile spans the whole azimuth extent
+        AzArgs a{};
+        a.tw_n = c->tw_all + n;
+        a.c1 = p->c1;
+        a.dt = 1.0 / p->p.sample_rate_hz;
+        a.t_start = p->p.t_start_fast_s;
+        a.scale = 1.0f / (float)n;
+        a.n_rg = p->n_rg;
         a.in = (const float2*)in; a.out = (float2*)out;
         a.tw_r = c->tw_all + n;
         a.in_q_stride = 0; a.in_m_stride = 1; a.out_q_stride = 0; a.out_m_stride = 1;
-        HIPCHK(c, launch_az_tile(n, p->az_w, inv, epi_last, a, 1, c->stream));
+        HIPCHK(c, launch_az_tile(n, p->az_w, inv, inv ? AZ_EPI_SCALE : AZ_EPI_PHI1, a, 1, c->stream));
         return SARX_OK;
     }
-    // step A: rows q + m*S, FFT over m (length RA), twiddle W_n^(q*m'), same rows out
-    a.in = (const float2*)in; a.out = (float2*)tmp;
-    a.tw_r = c->tw_all + RA;
-    a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
-    HIPCHK(c, launch_az_tile(RA, p->az_w, inv, AZ_EPI_TWIDDLE, a, S, c->stream));
-    // step B: rows q*S + m, FFT over m (length S), out rows q + m'*RA (natural bin order)
-    a.in = (const float2*)tmp; a.out = (float2*)out;
-    a.tw_r = c->tw_all + S;
-    a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
-    HIPCHK(c, launch_az_tile(S, p->az_w, inv, epi_last, a, RA, c->stream));
-    return SARX_OK;
+    int rc;
+    if ((rc = az_step(p, inv, false, S, in, tmp, 0, S)) != SARX_OK) return rc;
+    return az_step(p, inv, true, S, tmp, out, 0, n / S);
 }
 
 int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
@@ -461,7 +490,21 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
     sarx_ctx* c = p->ctx;
     hipSetDevice(c->device);
     if (!d_in || !d_out) return fail(c, SARX_ERR_INVALID, "NULL image pointer");
-    if (p->gen) return fail(c, SARX_ERR_UNSUPPORTED, "per-pass entry points exist for power-of-two plans only");
+    if (p->gen) {      // any-size plans: the range passes of a direct mixed-radix line length (13200) only
+        int mode = -1;
+        switch (pass_id) {
+            case SARX_PASS_RG_FFT_PHI2: mode = RG_FFT_PHI2; break;
+            case SARX_PASS_RG_IFFT_PHI3: mode = RG_IFFT_PHI3; break;
+            case SARX_PASS_RG_FUSED_23: mode = RG_FUSED; break;
+            case 100: mode = RG_FFT; break;
+            case 101: mode = RG_IFFT; break;
+        }
+        hipError_t e = mode < 0 ? hipErrorNotSupported : general_csa_range_pass(p->gen, mode, (const float2*)d_in, (float2*)d_out, c->stream);
+        if (e == hipErrorNotSupported)
+            return fail(c, SARX_ERR_UNSUPPORTED, "per-pass entry points exist for power-of-two plans and for the range passes of n_rg = 13200");
+        HIPCHK(c, e);
+        return SARX_OK;
+    }
     switch (pass_id) {
         case SARX_PASS_AZ_FFT_PHI1:
         case SARX_PASS_AZ_IFFT:
@@ -487,6 +530,31 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     if (p->gen) {
         float2* dst = rg_major ? p->buf_a : (float2*)d_image;
         HIPCHK(c, general_csa_focus(p->gen, (const float2*)d_phist, dst, c->stream));
+        if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
+        return SARX_OK;
+    }
+    if (p->slab_tiles > 0 && p->az_s != p->n_az && (p->flags & SARX_FUSE_RANGE)) {
+        // Slab mode.  The forward transform's second step, the fused range pass and the inverse transform's first step all
+        // work on the same row set when the inverse is split the other way round (its stride = the forward's tile count):
+        // forward tile q writes rows q + m'*RA (m' < S), the range pass needs whole rows, inverse tile q reads rows
+        // q + m*RA.  Running the three launches group of tiles by group of tiles keeps a group's rows (slab_tiles * S rows)
+        // in the 256 MiB Infinity Cache between them: the image makes three HBM round trips instead of five.
+        const int S = p->az_s, RA = p->n_az / S, Q = p->slab_tiles;
+        float2* last = rg_major ? p->buf_a : (float2*)d_image;
+        if ((rc = az_step(p, false, false, S, d_phist, d_image, 0, S)) != SARX_OK) return rc;       // forward step A, whole image
+        bool marked = false;
+        for (int q0 = 0; q0 < RA; q0 += Q) {
+            const int nq = (q0 + Q <= RA) ? Q : RA - q0;
+            if ((rc = az_step(p, false, true, S, d_image, p->buf_b, q0, nq)) != SARX_OK) return rc;
+            RangeArgs a = range_args(p, p->buf_b, p->buf_b);
+            a.n_az = nq * S; a.row0 = q0; a.row_inner = nq; a.row_stride = RA;
+            const bool mark = !marked && p->mark_start >= 0;          // the first group's launch is the one that is timed
+            if (mark) { HIPCHK(c, hipEventRecord(c->ev[p->mark_start], c->stream)); c->ev_set[p->mark_start] = true; }
+            HIPCHK(c, run_range(p, RG_FUSED, a));
+            if (mark && p->mark_stop >= 0) { HIPCHK(c, hipEventRecord(c->ev[p->mark_stop], c->stream)); c->ev_set[p->mark_stop] = true; marked = true; }
+            if ((rc = az_step(p, true, false, RA, p->buf_b, p->buf_b, q0, nq)) != SARX_OK) return rc;   // inverse step A, stride RA
+        }
+        if ((rc = az_step(p, true, true, RA, p->buf_b, last, 0, S)) != SARX_OK) return rc;           // inverse step B, whole image
         if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
         return SARX_OK;
     }
@@ -573,7 +641,7 @@ int sarx_rda_focus_host(sarx_rda_plan* p, const void* phist, float* mag, void* p
     if (!phist || !mag) return fail(c, SARX_ERR_INVALID, "NULL host pointer");
     const size_t px = (size_t)p->n_r * p->n_p;
     HIPCHK(c, hipMemcpyAsync(p->d_in, phist, px * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, rda_focus(p->r, p->d_in, c->stream));
+    HIPCHK(c, rda_focus(p->r, p->d_in, c->stream, nullptr, rc != nullptr));
     HIPCHK(c, hipMemcpyAsync(mag, rda_mag(p->r), px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     void* outs[3] = {pc, rd, rc};
     for (int i = 0; i < 3; ++i)
@@ -581,18 +649,16 @@ int sarx_rda_focus_host(sarx_rda_plan* p, const void* phist, float* mag, void* p
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SARX_OK;
 }
-int sarx_rda_focus_dev(sarx_rda_plan* p, const void* d_phist, float* mag, void* pc, void* rd, void* rc) {
+int sarx_rda_focus_dev(sarx_rda_plan* p, const void* d_phist, float* d_mag, void* d_pc, void* d_rd, void* d_rc) {
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
     sarx_ctx* c = p->ctx;
     hipSetDevice(c->device);
-    if (!d_phist || !mag) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (!d_phist || !d_mag) return fail(c, SARX_ERR_INVALID, "NULL pointer");
     const size_t px = (size_t)p->n_r * p->n_p;
-    HIPCHK(c, rda_focus(p->r, (const float2*)d_phist, c->stream));
-    HIPCHK(c, hipMemcpyAsync(mag, rda_mag(p->r), px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    void* outs[3] = {pc, rd, rc};
+    HIPCHK(c, rda_focus(p->r, (const float2*)d_phist, c->stream, d_mag, d_rc != nullptr));   // magnitude written in place by the last launch
+    void* outs[3] = {d_pc, d_rd, d_rc};
     for (int i = 0; i < 3; ++i)
-        if (outs[i]) HIPCHK(c, hipMemcpyAsync(outs[i], rda_stage(p->r, i), px * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (outs[i]) HIPCHK(c, hipMemcpyAsync(outs[i], rda_stage(p->r, i), px * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
     return SARX_OK;
 }
 int sarx_rda_axes(const sarx_rda_plan* p, double* range_centered, double* cross_range, double* doppler) {

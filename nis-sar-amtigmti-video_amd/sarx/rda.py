@@ -47,14 +47,15 @@ def _plan(ctx, n_r, n_p, prm):
 
 
 def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
-                  platform_speed_mps, range_grp_m, *, ctx=None, intermediates=True):
+                  platform_speed_mps, range_grp_m, *, ctx=None, intermediates=True, device_output=False):
     """phist: [num_ranges x num_pulses] complex (the scripts pass ``raw_data.T``); a NumPy array, or ``d.T`` of the
     [pulses x ranges] DeviceArray an echo generator returned with ``device=True`` (nothing is uploaded then).
 
     Returns the reference's 7-tuple (:447-448): (sar_image_mag.T [pulses x ranges], range_axis_centered,
     cross_range_m, phist_compressed, range_doppler, range_doppler_rcmc [ranges x pulses each], doppler_freq).
     Images are float32 / complex64.  ``intermediates=False`` skips downloading the three complex maps
-    (they come back as None).
+    (they come back as None).  ``device_output=True`` (device input only) leaves the images on the GPU: the tuple then
+    holds DeviceBuffers ([pulses x ranges] row-major: float32 magnitude, complex64 maps) and nothing is downloaded.
     """
     on_device = isinstance(phist, DeviceArray)
     if on_device:
@@ -74,12 +75,25 @@ def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     prm = _ffi.RadarParams(center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
                            platform_speed_mps, range_grp_m, 0.0)
     plan = _plan(ctx, n_r, n_p, prm)
-    mag = np.empty((n_p, n_r), dtype=np.float32)
-    stages = [np.empty((n_p, n_r), dtype=np.complex64) if intermediates else None for _ in range(3)]
-    ptr = [s.ctypes.data if s is not None else None for s in stages]
-    if on_device:
-        check(lib.sarx_rda_focus_dev(plan.h, phist.ptr, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
+    if on_device:          # device in, device out: only what the caller wants is downloaded afterwards
+        d_mag = ctx.alloc(n_p * n_r * 4)
+        d_st = [ctx.alloc(n_p * n_r * 8) if intermediates else None for _ in range(3)]
+        check(lib.sarx_rda_focus_dev(plan.h, phist.ptr, d_mag.ptr, *[b.ptr if b is not None else None for b in d_st]), ctx.h)
+        if device_output:
+            r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
+            check(lib.sarx_rda_axes(plan.h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
+            return (d_mag, r_ax, c_ax, *d_st, fd)
+        mag = d_mag.download(np.float32, (n_p, n_r))
+        stages = [b.download(np.complex64, (n_p, n_r)) if b is not None else None for b in d_st]
+        for b in (d_mag, *d_st):
+            if b is not None:
+                b.release()
     else:
+        if device_output:
+            raise ValueError("device_output needs a device input (DeviceArray .T)")
+        mag = np.empty((n_p, n_r), dtype=np.float32)
+        stages = [np.empty((n_p, n_r), dtype=np.complex64) if intermediates else None for _ in range(3)]
+        ptr = [s.ctypes.data if s is not None else None for s in stages]
         check(lib.sarx_rda_focus_host(plan.h, x.ctypes.data, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
     r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
     check(lib.sarx_rda_axes(plan.h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)

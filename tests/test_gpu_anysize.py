@@ -25,7 +25,10 @@ def test_reference_fixture_96x80():
 
 
 @pytest.mark.parametrize("n_az,n_rg", [(255, 257), (300, 200), (5, 7), (64, 100), (100, 64), (33, 1024),
-                                       (48, 13200),      # native range extent: chirp-z over a 32768-point line
+                                       (48, 13200),      # native range extent: direct 24 x 22 x 25 lines; azimuth chirp-z in one step
+                                       (300, 13200),     # ... with the three-launch azimuth chirp-z (1024 rows) around it
+                                       (256, 13200),     # ... with direct two-step azimuth transforms
+                                       (64, 13200),      # ... with direct one-step azimuth transforms
                                        (7199, 48),       # native azimuth extent: chirp-z over 16384 rows
                                        (9001, 40),       # chirp-z over 32768 rows (128 x 256 column transform)
                                        (32768, 32),      # the largest azimuth extent, direct
@@ -54,3 +57,88 @@ def test_point_targets_focus_at_native_like_size():
     img = sarx.sar_focus_csa(raw, *args)[0]
     assert np.unravel_index(np.argmax(np.abs(img)), img.shape) == np.unravel_index(np.argmax(np.abs(ref)), ref.shape)
     assert orc.rel_l2(np.abs(img), np.abs(ref)) < TOL
+
+
+def test_mixed_radix_13200_range_passes():
+    """The direct line kernels of the reference's native range extent (13200 = 24 x 22 x 25, range_mixed.hip), every mode,
+    more lines than workgroups so the persistent loop runs more than once."""
+    import sarx
+    from sarx import _ffi
+    n_az, n_rg = 600, 13200
+    ctx = sarx.default_context()
+    k = orc.scaled_radar(n_az, n_rg)
+    args = orc.focus_args(k)
+    plan = sarx.CsaPlan(ctx, n_az, n_rg, *args)
+    r = np.random.default_rng(13200)
+    x = (r.standard_normal((n_az, n_rg)) + 1j * r.standard_normal((n_az, n_rg))).astype(np.complex64)
+    d_a, d_b = ctx.to_device(x), ctx.alloc(x.nbytes)
+
+    def run(pid, src=None):
+        if src is not None:
+            d_a.upload(src.astype(np.complex64))
+        plan.run_pass(pid, d_a, d_b)
+        return d_b.download(np.complex64, x.shape)
+
+    f = np.fft.fft(x.astype(np.complex128), axis=1)
+    assert orc.rel_l2(run(_ffi.PASS_TEST_RG_FFT), f) < 3e-6
+    assert orc.rel_l2(run(_ffi.PASS_TEST_RG_IFFT, f / 100.0), x / 100.0) < 3e-6
+    bins = np.arange(n_az)
+    o2, o3 = orc.range_chain_rows(x, bins, n_az, *args)
+    assert orc.rel_l2(run(_ffi.PASS_RG_FFT_PHI2, x), o2) < 5e-6
+    assert orc.rel_l2(run(_ffi.PASS_RG_IFFT_PHI3, o2), o3) < 5e-6
+    g3 = run(_ffi.PASS_RG_FUSED_23, x)
+    assert orc.rel_l2(g3, o3) < 5e-6
+    per_row = np.linalg.norm(g3 - o3, axis=1) / np.linalg.norm(o3, axis=1)
+    assert per_row.max() < 1e-5, (int(per_row.argmax()), per_row.max())
+    d_a.upload(x)
+    plan.run_pass(_ffi.PASS_RG_FUSED_23, d_a, d_a)                 # in place, as the focus runs it
+    np.testing.assert_array_equal(d_a.download(np.complex64, x.shape), g3)
+    with pytest.raises(sarx.SarxError):
+        plan.run_pass(_ffi.PASS_AZ_IFFT, d_a, d_b)                 # azimuth passes of any-size plans have no per-pass entry
+    plan.close()
+
+
+def test_direct_lines_equal_chirp_z_lines(monkeypatch):
+    """SARX_RANGE_MIXED=0 keeps the chirp-z range route: both routes give the same image."""
+    import sarx
+    ctx = sarx.default_context()
+    n_az, n_rg = 300, 13200
+    k = orc.scaled_radar(n_az, n_rg)
+    args = orc.focus_args(k)
+    r = np.random.default_rng(5)
+    x = (r.standard_normal((n_az, n_rg)) + 1j * r.standard_normal((n_az, n_rg))).astype(np.complex64)
+    d_in, d_a, d_b = ctx.to_device(x), ctx.alloc(x.nbytes), ctx.alloc(x.nbytes)
+    direct = sarx.CsaPlan(ctx, n_az, n_rg, *args)
+    monkeypatch.setenv("SARX_RANGE_MIXED", "0")
+    chirpz = sarx.CsaPlan(ctx, n_az, n_rg, *args)
+    monkeypatch.delenv("SARX_RANGE_MIXED")
+    direct.focus_dev(d_in, d_a)
+    chirpz.focus_dev(d_in, d_b)
+    a, b = d_a.download(np.complex64, x.shape), d_b.download(np.complex64, x.shape)
+    assert orc.rel_l2(a, b) < 1e-5
+    assert chirpz.scratch_bytes() > direct.scratch_bytes()         # no per-row convolution spectra on the direct route
+    direct.close()
+    chirpz.close()
+
+
+def test_native_scene_size_vs_oracle():
+    """The reference's own scene, 7199 pulses x 13200 samples (sar_ati_dcpa_sim_csa.py:47,111,402), with its literal radar
+    constants: the whole image against the oracle (row-blocked complex128)."""
+    import sarx
+    from sarx import radar
+    n_az, n_rg = 7199, 13200
+    ctx = sarx.default_context()
+    args = radar.focus_args()                                       # the reference's constants and 22 us window (:18-38,112)
+    plan = sarx.CsaPlan(ctx, n_az, n_rg, *args)
+    px = n_az * n_rg
+    d_in, d_out = ctx.alloc(px * 8), ctx.alloc(px * 8)
+    ctx.fill_noise(d_in, px, 7199)
+    plan.focus_dev(d_in, d_out)
+    raw = d_in.download(np.complex64, (n_az, n_rg))
+    img = d_out.download(np.complex64, (n_az, n_rg))
+    ref = orc.sar_focus_csa_lean(raw, *args, workers=8, block=64)[0]
+    assert orc.rel_l2(img.T, ref) < TOL
+    assert orc.rel_l2(np.abs(img.T), np.abs(ref)) < TOL
+    d_in.release()
+    d_out.release()
+    plan.close()

@@ -233,3 +233,37 @@ def test_8192_two_channel_point_targets_vs_oracle(sx, ctx):
     assert (res["ati_phase_masked"][~m & (res["slc1_mag"] < 0.049 * ref["max_mag"])] == 0).all()
     # physics: the radial mover shows an ATI phase the stationary grid does not
     assert np.abs(ref["ati_phase"][m]).max() > 0.2
+
+
+# ---- slab mode: same image, three HBM round trips ---------------------------------------------------------------------
+@pytest.mark.parametrize("n_az,n_rg,mib", [(4096, 2048, 8), (2048, 4096, 16), (8192, 1024, 4), (1024, 16384, 32), (4096, 4096, 1)])
+def test_slab_mode_equals_default(sx, ctx, monkeypatch, n_az, n_rg, mib):
+    """SARX_SLAB_MIB groups the forward transform's second step, the fused range pass and the inverse transform's first
+    step by tiles (sarx_csa_focus_dev).  Square splits (n_az = 4^k) run the same kernels on the same data in another
+    order: bit-identical; the others split the inverse transform the other way round: same image to rounding."""
+    from sarx import _ffi
+    raw, k = orc.point_scene(n_az, n_rg, seed=n_az + n_rg, clutter_db=-20.0, n_targets=3) if n_az * n_rg <= (1 << 23) else (None, None)
+    if raw is None:
+        k = orc.scaled_radar(n_az, n_rg)
+        r = np.random.default_rng(1)
+        raw = (r.standard_normal((n_az, n_rg), dtype=np.float32) + 1j * r.standard_normal((n_az, n_rg), dtype=np.float32)).astype(np.complex64)
+    args = orc.focus_args(k)
+    base = sx.CsaPlan(ctx, n_az, n_rg, *args, flags=_ffi.FUSE_RANGE)
+    monkeypatch.setenv("SARX_SLAB_MIB", str(mib))
+    slab = sx.CsaPlan(ctx, n_az, n_rg, *args, flags=_ffi.FUSE_RANGE)
+    monkeypatch.delenv("SARX_SLAB_MIB")
+    d_in, d_a, d_b = ctx.to_device(raw), ctx.alloc(raw.nbytes), ctx.alloc(raw.nbytes)
+    base.focus_dev(d_in, d_a)
+    slab.focus_dev(d_in, d_b)
+    a, b = d_a.download(np.complex64, raw.shape), d_b.download(np.complex64, raw.shape)
+    l2 = int(np.log2(n_az))
+    if l2 % 2 == 0:
+        np.testing.assert_array_equal(a, b)
+    else:
+        assert orc.rel_l2(b, a) < 2e-6
+    if n_az * n_rg <= (1 << 23):
+        assert orc.rel_l2(b.T, orc.sar_focus_csa(raw, *args)[0]) < TOL
+    for buf in (d_in, d_a, d_b):
+        buf.release()
+    base.close()
+    slab.close()

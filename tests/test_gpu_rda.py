@@ -85,6 +85,35 @@ def test_rda_device_input_equals_host_input():
     d.release()
 
 
+@pytest.mark.parametrize("n_r,n_p", [(512, 300), (300, 1000), (256, 256)])
+def test_rda_device_outputs_stay_on_the_gpu(n_r, n_p):
+    """device_output=True: magnitude and maps come back as device buffers (the C call only enqueues); their content is
+    what the host path returns.  (512, 300) and (300, 1000) take the three-launch chirp-z along pulses - shifts, window
+    and magnitude folded into its ends - (256, 256) the direct power-of-two route."""
+    import sarx
+    phist, args = rda.rda_scene(n_r, n_p, seed=n_r * 7 + n_p)
+    raw = np.ascontiguousarray(phist.T)
+    ctx = sarx.default_context()
+    d = sarx.DeviceArray(ctx.to_device(raw), raw.shape)
+    host = sarx.sar_focus_rda(raw.T, *args)
+    dev = sarx.sar_focus_rda(d.T, *args, device_output=True)
+    np.testing.assert_array_equal(dev[0].download(np.float32, (n_p, n_r)), host[0])
+    for i in (3, 4, 5):
+        np.testing.assert_array_equal(dev[i].download(np.complex64, (n_p, n_r)).T, host[i])
+    for i in (1, 2, 6):
+        np.testing.assert_array_equal(dev[i], host[i])
+    # without the intermediates the RCMC map is not even stored; the image is the same
+    lean = sarx.sar_focus_rda(d.T, *args, intermediates=False, device_output=True)
+    assert lean[3] is None and lean[5] is None
+    np.testing.assert_array_equal(lean[0].download(np.float32, (n_p, n_r)), host[0])
+    _check(host, rda.sar_focus_rda(phist, *args))
+    for b in (dev[0], dev[3], dev[4], dev[5], lean[0]):
+        b.release()
+    d.release()
+    with pytest.raises(ValueError):
+        sarx.sar_focus_rda(raw.T, *args, device_output=True)
+
+
 def test_rda_errors():
     import sarx
     phist, args = rda.rda_scene(64, 32, seed=1)

@@ -1,0 +1,49 @@
+import itertools
+N,R1,R2,R3,T=13200,24,22,25,640
+def conflicts(addrs_per_lane, write):
+    """addrs: list over lanes (64) of element address (8-byte elements) or None (inactive). returns LDS cycles."""
+    cyc=0
+    if write:
+        groups=[range(g*16,g*16+16) for g in range(4)]; nb=32
+    else:
+        groups=[range(0,32),range(32,64)]; nb=64
+    for g in groups:
+        banks={}
+        for l in g:
+            a=addrs_per_lane[l]
+            if a is None: continue
+            for d in (0,1):
+                b=(2*a+d)%nb
+                banks.setdefault(b,set()).add(2*a+d)
+        cyc+=max([len(v) for v in banks.values()],default=0)
+    return cyc
+def total(fn, nthreads, R, write):
+    tot=0;ideal=0
+    for w0 in range(0,T,64):
+        for r in range(R):
+            lanes=[fn(t,r) if t<nthreads else None for t in range(w0,w0+64)]
+            if all(a is None for a in lanes): continue
+            tot+=conflicts(lanes,write); ideal+= (4 if write else 2)
+    return tot,ideal
+G1,G2,G3=N//R1,N//R2,N//R3
+best={}
+for p in range(0,17):
+    pitch1=G1+p
+    w=total(lambda j,r: r*pitch1+j, G1, R1, True)
+    rd=total(lambda j,r: (j%R1)*pitch1+(j//R1)+R3*r, G2, R2, False)
+    print('ex1 p',p,'write',w,'read',rd)
+for p in range(0,17):
+    pitch2=G3+p
+    w=total(lambda j,r: (j//R1)*pitch2+(j%R1)+R1*r, G2, R2, True)
+    rd=total(lambda j,r: j+r*pitch2, G3, R3, False)
+    print('ex2 p',p,'write',w,'read',rd)
+for p in range(0,17):
+    pitch3=G3+p
+    w=total(lambda j,r: r*pitch3+j, G3, R3, True)
+    rd=total(lambda j,r: (j%R3)*pitch3+(j//R3)+R1*r, G2, R2, False)
+    print('ex3 p',p,'write',w,'read',rd)
+for p in range(0,17):
+    pitch4=G1+p
+    w=total(lambda j,r: (j//R3)*pitch4+(j%R3)+R3*r, G2, R2, True)
+    rd=total(lambda j,r: j+r*pitch4, G1, R1, False)
+    print('ex4 p',p,'write',w,'read',rd)
