@@ -1,0 +1,210 @@
+// Azimuth transforms of the reference's native pulse count without chirp-z: 7199 = 23 * 313 (sar_ati_dcpa_sim_csa.py:47,
+// 402-403: 7200 pulses minus the DPCA shift), both factors prime and coprime.
+//
+//   Good-Thomas (prime-factor) map, no twiddles between the factors:
+//       n = (313 n1 + 23 n2) mod 7199,      k = (c1 k1 + c2 k2) mod 7199,  c1 = 313 (313^-1 mod 23), c2 = 23 (23^-1 mod 313)
+//       X[k] = sum_n1 W_23^(n1 k1) [ sum_n2 x[n] W_313^(n2 k2) ]
+//   launch 1 (pfa_rader313_kernel): the 313-point transforms over n2, one (n1, column tile) per workgroup, by Rader's
+//       algorithm: with g a primitive root mod 313,  y[g^-m] = a[0] + (a' (*) w')[m],  a'[q] = a[g^q],  w'[q] = W_313^(g^-q),
+//       a cyclic convolution of length 312 = 24 * 13 done as FFT_312 . spectrum of w' . IFFT_312 on a [312 x W] LDS
+//       image (two Stockham stages each way, in-register DFT-24 / DFT-13 of fft_mixed.hpp); y[0] = a[0] + DC bin.
+//       The permutations g^q / g^-m are folded into the row addresses of the global loads and stores, so the image makes
+//       one HBM round trip: rows of the dense source in, rows n1*313 + k2 of the intermediate out.
+//   launch 2 (pfa_dft23_kernel): the 23-point transforms over n1 entirely in registers (one thread per (k2, column)),
+//       the output row permutation k(k1, k2), and the epilogue (Phi_1, sar_ati_dcpa_sim_csa.py:262-274, or the 1/N of
+//       the inverse) on the way out.
+// Two HBM round trips of the unpadded [7199 x n_rg] image per transform; the chirp-z route over 16384 rows moved 5.5x
+// the bytes in three launches.
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#include "csa_kernels.h"
+#include "fft_mixed.hpp"
+#include "phase.hpp"
+
+namespace sarx {
+
+namespace pfa {
+constexpr int N = 7199, N1 = 23, P = 313, L = 312, RA = 24, RB = 13;
+static_assert(N1 * P == N && RA * RB == L, "factorisation");
+}  // namespace pfa
+
+// 313-point DFTs along rows n = (313 n1 + 23 n2) mod 7199 of a.in, column tile of W samples; result rows n1*313 + k2 of a.u
+template <int W>
+__global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
+    using namespace pfa;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);                   // [312][W]
+    int* s_gpow = reinterpret_cast<int*>(lds + (size_t)L * W);   // g^q mod 313
+    int* s_ginv = s_gpow + L;                                    // g^-m mod 313
+    const int c = threadIdx.x % W, j = threadIdx.x / W;          // j in [0, 24)
+    const int col = blockIdx.x * W + c, n1 = blockIdx.y;
+    const bool live = col < a.in_cols;
+    const int base1 = P * n1;
+    for (int i = threadIdx.x; i < L; i += RA * W) { s_gpow[i] = a.gpow[i]; s_ginv[i] = a.ginv[i]; }
+    __syncthreads();
+
+    cf v[RA];
+    cf a0 = make_float2(0.f, 0.f), y0 = a0;
+    // forward FFT_312, stage 1: radix 24 on a'[j + 13 r], butterflies j < 13, straight from HBM
+    if (j < RB) {
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            int row = base1 + N1 * s_gpow[j + RB * r];
+            if (row >= N) row -= N;
+            v[r] = live ? a.in[(size_t)row * a.in_ld + col] : make_float2(0.f, 0.f);
+        }
+        if (j == 0 && live) a0 = a.in[(size_t)base1 * a.in_ld + col];          // n2 = 0
+        mix::dft_any<RA, false>(v);
+#pragma unroll
+        for (int r = 0; r < RA; ++r) lds[(size_t)(j * RA + r) * W + c] = v[r];
+    }
+    __syncthreads();
+    // stage 2: radix 13 on y[j + 24 r], twiddle W_312^(j r); thread j ends with spectrum bins j + 24 r
+#pragma unroll
+    for (int r = 0; r < RB; ++r) v[r] = lds[(size_t)(j + RA * r) * W + c];
+    mix::apply_powers<RB>(v, cis_frac(-(float)j * (1.0f / (float)L)));
+    mix::dft_any<RB, false>(v);
+    // times the spectrum of w' (carries the 1/312 of the convolution); the DC bin also gives y[0] and takes a[0]
+    if (j == 0) y0 = cadd(a0, v[0]);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) v[r] = cmul(v[r], a.bspec[j + RA * r]);
+    if (j == 0) v[0] = cadd(v[0], a0);
+    // inverse FFT_312, radices reversed: stage 1 radix 13 on the registers as they are
+    mix::dft_any<RB, true>(v);
+    __syncthreads();                                             // stage 2's reads of the image are finished
+#pragma unroll
+    for (int r = 0; r < RB; ++r) lds[(size_t)(j * RB + r) * W + c] = v[r];
+    __syncthreads();
+    // stage 2: radix 24 on z[j + 13 r], twiddle W_312^(-j r), butterflies j < 13; outputs m = j + 13 r go to k2 = g^-m
+    if (j < RB) {
+#pragma unroll
+        for (int r = 0; r < RA; ++r) v[r] = lds[(size_t)(j + RB * r) * W + c];
+        mix::apply_powers<RA>(v, cis_frac((float)j * (1.0f / (float)L)));
+        mix::dft_any<RA, true>(v);
+        if (col < a.u_cols) {
+#pragma unroll
+            for (int r = 0; r < RA; ++r) a.u[(size_t)(base1 + s_ginv[j + RB * r]) * a.u_ld + col] = v[r];
+            if (j == 0) a.u[(size_t)base1 * a.u_ld + col] = y0;
+        }
+    }
+}
+
+// 23-point DFTs over n1 of rows n1*313 + k2 of a.u, in registers; output row k = (c2 k2 + c1 k1) mod 7199
+// EPI: 0 none, 1 times Phi_1(row, col) (forward), 2 times a.scale (inverse)
+template <bool INV, int EPI>
+__global__ __launch_bounds__(256) void pfa_dft23_kernel(PfaArgs a) {
+    using namespace pfa;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int k2 = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= a.out_cols || k2 >= P) return;
+    cf v[N1];
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) v[n1] = a.u[(size_t)(n1 * P + k2) * a.u_ld + col];
+    mix::dft_any<N1, INV>(v);
+    int row = (int)(((long long)a.c2k * k2) % N);
+#pragma unroll
+    for (int k1 = 0; k1 < N1; ++k1) {
+        cf x = v[k1];
+        if constexpr (EPI == 1) x = cmul(x, phi1(col, a.c1[row], a.dt, a.t_start));
+        else if constexpr (EPI == 2) { x.x *= a.scale; x.y *= a.scale; }
+        a.out[(size_t)row * a.out_ld + col] = x;
+        row += a.c1k;
+        if (row >= N) row -= N;
+    }
+}
+
+bool az_pfa_supported(int n_az) { return n_az == pfa::N; }
+
+// ---- host tables ------------------------------------------------------------------------------------------------------
+static int pow_mod(long long b, long long e, long long m) {
+    long long r = 1;
+    b %= m;
+    while (e > 0) { if (e & 1) r = r * b % m; b = b * b % m; e >>= 1; }
+    return (int)r;
+}
+static int inv_mod(int a, int m) { return pow_mod(a, m - 2, m); }     // m prime
+
+struct AzPfa {
+    int *gpow = nullptr, *ginv = nullptr;
+    cf *bspec_f = nullptr, *bspec_i = nullptr;
+    int c1k = 0, c2k = 0;
+};
+void az_pfa_destroy(AzPfa* z) {
+    if (!z) return;
+    hipFree(z->gpow); hipFree(z->ginv); hipFree(z->bspec_f); hipFree(z->bspec_i);
+    delete z;
+}
+AzPfa* az_pfa_create(hipError_t* err) {
+    using namespace pfa;
+    AzPfa* z = new AzPfa();
+    int g = 2;                                                   // smallest primitive root mod 313: order exactly 312 = 2^3 * 3 * 13
+    for (;; ++g)
+        if (pow_mod(g, L / 2, P) != 1 && pow_mod(g, L / 3, P) != 1 && pow_mod(g, L / 13, P) != 1) break;
+    std::vector<int> gpow(L), ginv(L);
+    for (int q = 0; q < L; ++q) gpow[q] = pow_mod(g, q, P);
+    for (int m = 0; m < L; ++m) ginv[m] = gpow[(L - m) % L];
+    // spectrum of w'[q] = exp(s 2 pi i g^-q / 313), forward FFT_312, divided by 312, for both signs s
+    std::vector<cf> bf(L), bi(L);
+    for (int dir = 0; dir < 2; ++dir) {
+        const double s = dir == 0 ? -1.0 : 1.0;
+        for (int k = 0; k < L; ++k) {
+            std::complex<double> acc(0, 0);
+            for (int q = 0; q < L; ++q) {
+                const double aw = s * 2.0 * M_PI * (double)ginv[q] / (double)P;
+                const double af = -2.0 * M_PI * (double)((long long)q * k % L) / (double)L;
+                acc += std::polar(1.0, aw + af);
+            }
+            acc /= (double)L;
+            (dir == 0 ? bf : bi)[k] = make_float2((float)acc.real(), (float)acc.imag());
+        }
+    }
+    z->c1k = P * inv_mod(P % N1, N1);
+    z->c2k = N1 * inv_mod(N1 % P, P);
+    hipError_t e = hipSuccess;
+    auto up = [&](const void* h, size_t bytes, void** d) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(d, bytes);
+        if (e == hipSuccess) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    up(gpow.data(), L * sizeof(int), (void**)&z->gpow);
+    up(ginv.data(), L * sizeof(int), (void**)&z->ginv);
+    up(bf.data(), L * sizeof(cf), (void**)&z->bspec_f);
+    up(bi.data(), L * sizeof(cf), (void**)&z->bspec_i);
+    if (err) *err = e;
+    if (e != hipSuccess) { az_pfa_destroy(z); return nullptr; }
+    return z;
+}
+
+// src: dense [7199 x src_cols] (leading dimension src_ld); u: work array [7199 x u_ld], u_ld >= dst_cols;
+// dst: dense [7199 x dst_cols]; epi: 0 none, 1 Phi_1 (a.c1 / dt / t_start must be set), 2 scale
+hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, int src_cols, cf* u, size_t u_ld, cf* dst,
+                      size_t dst_ld, int dst_cols, int epi, const double2* c1, double dt, double t_start, float scale,
+                      hipStream_t st) {
+    using namespace pfa;
+    constexpr int W = 32;
+    PfaArgs a{};
+    a.in = src; a.in_ld = src_ld; a.in_cols = src_cols;
+    a.u = u; a.u_ld = u_ld; a.u_cols = (int)(u_ld < (size_t)dst_cols ? u_ld : (size_t)dst_cols);
+    a.out = dst; a.out_ld = dst_ld; a.out_cols = dst_cols;
+    a.gpow = z->gpow; a.ginv = z->ginv; a.bspec = inv ? z->bspec_i : z->bspec_f;
+    a.c1 = c1; a.dt = dt; a.t_start = t_start; a.scale = scale; a.c1k = z->c1k; a.c2k = z->c2k;
+    const size_t lds = (size_t)L * W * sizeof(cf) + 2 * L * sizeof(int);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfa_rader313_kernel<W>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pfa_rader313_kernel<W>, dim3((dst_cols + W - 1) / W, N1), dim3(RA * W), lds, st, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    dim3 g2((dst_cols + 63) / 64, (P + 3) / 4);
+    if (!inv) {
+        if (epi == 1) hipLaunchKernelGGL((pfa_dft23_kernel<false, 1>), g2, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((pfa_dft23_kernel<false, 0>), g2, dim3(256), 0, st, a);
+    } else {
+        if (epi == 2) hipLaunchKernelGGL((pfa_dft23_kernel<true, 2>), g2, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((pfa_dft23_kernel<true, 0>), g2, dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace sarx

@@ -92,6 +92,26 @@ hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int 
 // transform's second step and the inverse transform's first step on one HBM round trip.
 hipError_t launch_az_conv(int s, int ra, const AzArgs& a, hipStream_t st);
 
+// az_pfa.hip: prime-factor (23 x 313) azimuth transforms of the reference's native 7199 pulses, Rader for the 313
+struct PfaArgs {
+    const float2* in; size_t in_ld; int in_cols;      // dense source [7199 x in_cols]
+    float2* u; size_t u_ld; int u_cols;                // intermediate, rows n1*313 + k2
+    float2* out; size_t out_ld; int out_cols;         // dense destination, rows in natural bin / pulse order
+    const int* gpow; const int* ginv;                  // g^q, g^-m mod 313 (312 each)
+    const float2* bspec;                               // spectrum of the Rader kernel w' / 312, for the transform's sign
+    const double2* c1; double dt, t_start;             // Phi_1 epilogue
+    float scale;                                       // inverse: 1/7199
+    int c1k, c2k;                                      // output map k = (c1k k1 + c2k k2) mod 7199
+};
+struct AzPfa;
+bool az_pfa_supported(int n_az);
+AzPfa* az_pfa_create(hipError_t* err);
+void az_pfa_destroy(AzPfa* z);
+// epi: 0 none, 1 times Phi_1 (forward), 2 times scale (inverse).  src may equal dst; u is a [7199 x u_ld] work array
+hipError_t az_pfa_run(const AzPfa* z, bool inv, const float2* src, size_t src_ld, int src_cols, float2* u, size_t u_ld,
+                      float2* dst, size_t dst_ld, int dst_cols, int epi, const double2* c1, double dt, double t_start,
+                      float scale, hipStream_t st);
+
 // products.hip
 struct AtiArgs {
     const float2* s1;

@@ -19,6 +19,8 @@ uint64_t general_csa_bytes(const GeneralCsa* g);
 // one range pass (RangeMode) on a dense [n_az x n_rg] image; hipErrorNotSupported unless the range extent has a direct
 // mixed-radix line kernel (range_mixed.hip)
 hipError_t general_csa_range_pass(GeneralCsa* g, int mode, const float2* in, float2* out, hipStream_t st);
+// one azimuth pass (forward + Phi_1 / inverse) on dense images; hipErrorNotSupported unless n_az = 7199 on the direct route
+hipError_t general_csa_az_pass(GeneralCsa* g, bool inv, const float2* in, float2* out, hipStream_t st);
 
 // building blocks shared with tdbp.hip
 // in-place line FFTs of `rows` contiguous lines of length m (power of two, 16..32768); the inverse carries 1/m.

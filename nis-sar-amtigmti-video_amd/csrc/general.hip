@@ -138,6 +138,7 @@ struct GeneralCsa {
     size_t work_elems = 0;
     cf* ktab = nullptr;          // [n_az x rg.m]: spectrum of the range convolution kernel IFFT_N(Phi_2) per azimuth bin (see below)
     bool rg_mixed = false;       // the range extent has a direct mixed-radix line kernel (range_mixed.hip): no chirp-z along range
+    AzPfa* pfa = nullptr;        // n_az = 7199: prime-factor azimuth transforms (az_pfa.hip) instead of chirp-z, on the rg_mixed route
     int cus = 256;               // compute units of the device (persistent grids)
     uint64_t bytes = 0;
 };
@@ -418,6 +419,17 @@ hipError_t general_csa_range_pass(GeneralCsa* g, int mode, const float2* in, flo
     return launch_range_mixed(g->n_rg, mode, a, g->cus, st);
 }
 
+// one azimuth pass (forward + Phi_1, or inverse with 1/n_az) of the plan's geometry on dense [n_az x n_rg] images
+// (prime-factor pulse counts only; `in` is not modified, in != out)
+hipError_t general_csa_az_pass(GeneralCsa* g, bool inv, const float2* in, float2* out, hipStream_t st) {
+    if (!g->pfa) return hipErrorNotSupported;
+    const int n_rg = g->n_rg;
+    if (!inv)
+        return az_pfa_run(g->pfa, false, in, n_rg, n_rg, g->work_a, g->ldc, out, n_rg, n_rg, 1, g->c1, 1.0 / g->p.sample_rate_hz,
+                          g->p.t_start_fast_s, 1.0f, st);
+    return az_pfa_run(g->pfa, true, in, n_rg, n_rg, g->work_a, g->ldc, out, n_rg, n_rg, 2, nullptr, 0.0, 0.0, 1.0f / (float)g->n_az, st);
+}
+
 // sar_focus_csa (:233-385) at any size.  Buffers: wa/wb [m_az x ldc] for the column transforms, work_a doubles as
 // the [n_az x m_rg] line-transform array when the range axis is not a power of two (else the dense image `data`).
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st) {
@@ -427,6 +439,12 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
     if (g->rg_mixed) {
         // the range extent has a direct line kernel (13200): no chirp-z along range, one fused launch for :278-382
         const bool z3 = !az.direct && cols_two_step(az.m);
+        if (g->pfa) {                 // 7199 = 23 x 313 pulses: prime-factor transforms, two launches each, no padding at all
+            const double dt = 1.0 / g->p.sample_rate_hz;
+            GCK(az_pfa_run(g->pfa, false, d_in, n_rg, n_rg, wa, ld, g->data, n_rg, n_rg, 1, g->c1, dt, g->p.t_start_fast_s, 1.0f, st));
+            GCK(general_csa_range_pass(g, RG_FUSED, g->data, g->data, st));
+            return az_pfa_run(g->pfa, true, g->data, n_rg, n_rg, wa, ld, d_out, n_rg, n_rg, 2, nullptr, 0.0, 0.0, 1.0f / (float)n_az, st);
+        }
         if (z3) {                     // azimuth FFT (:233) as a three-launch chirp-z with Phi_1 (:272-274) in its last epilogue
             const ColsSrc src{d_in, (size_t)n_rg, n_az, n_rg, az.chirp_f};
             const ColsDst dst{g->data, (size_t)n_rg, n_az, n_rg, az.chirp_f, 1.0f};
@@ -769,6 +787,7 @@ uint64_t general_csa_bytes(const GeneralCsa* g) { return g->bytes; }
 
 void general_csa_destroy(GeneralCsa* g) {
     if (!g) return;
+    az_pfa_destroy(g->pfa);
     axis_free(g->az); axis_free(g->rg);
     hipFree(g->c1); hipFree(g->c2); hipFree(g->c3);
     hipFree(g->data); hipFree(g->work_a); hipFree(g->work_b); hipFree(g->ktab);
@@ -784,6 +803,12 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
     if (cus > 0) g->cus = cus;
     const char* mv = getenv("SARX_RANGE_MIXED");          // SARX_RANGE_MIXED=0 keeps the chirp-z range path (A/B measurements)
     g->rg_mixed = csa_tables && range_mixed_supported(n_rg) && !(mv && atoi(mv) == 0);
+    const char* pv = getenv("SARX_AZ_PFA");               // SARX_AZ_PFA=0 keeps the chirp-z azimuth route (A/B measurements)
+    if (g->rg_mixed && az_pfa_supported(n_az) && !(pv && atoi(pv) == 0)) {
+        hipError_t pe = hipSuccess;
+        g->pfa = az_pfa_create(&pe);
+        if (!g->pfa) { err = std::string("prime-factor tables: ") + hipGetErrorString(pe); general_csa_destroy(g); return nullptr; }
+    }
     auto bail = [&](const char* what, hipError_t e) {
         err = std::string(what) + ": " + hipGetErrorString(e);
         general_csa_destroy(g);

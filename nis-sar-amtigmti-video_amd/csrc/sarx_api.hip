@@ -499,9 +499,15 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
             case 100: mode = RG_FFT; break;
             case 101: mode = RG_IFFT; break;
         }
-        hipError_t e = mode < 0 ? hipErrorNotSupported : general_csa_range_pass(p->gen, mode, (const float2*)d_in, (float2*)d_out, c->stream);
+        hipError_t e = hipErrorNotSupported;
+        if (mode >= 0) e = general_csa_range_pass(p->gen, mode, (const float2*)d_in, (float2*)d_out, c->stream);
+        else if (pass_id == SARX_PASS_AZ_FFT_PHI1 || pass_id == SARX_PASS_AZ_IFFT) {
+            if (d_in == d_out) return fail(c, SARX_ERR_INVALID, "azimuth passes are out-of-place");
+            e = general_csa_az_pass(p->gen, pass_id == SARX_PASS_AZ_IFFT, (const float2*)d_in, (float2*)d_out, c->stream);
+        }
         if (e == hipErrorNotSupported)
-            return fail(c, SARX_ERR_UNSUPPORTED, "per-pass entry points exist for power-of-two plans and for the range passes of n_rg = 13200");
+            return fail(c, SARX_ERR_UNSUPPORTED, "per-pass entry points exist for power-of-two plans, for the range passes of n_rg = 13200 "
+                                                 "and for the azimuth passes of 7199 x 13200");
         HIPCHK(c, e);
         return SARX_OK;
     }

@@ -142,3 +142,56 @@ def test_native_scene_size_vs_oracle():
     d_in.release()
     d_out.release()
     plan.close()
+
+
+def test_prime_factor_azimuth_passes_at_native_size():
+    """7199 = 23 x 313 pulses: Good-Thomas map + Rader's algorithm for the 313 (az_pfa.hip), forward with Phi_1 and
+    inverse, columns sampled against numpy.fft through the oracle's per-column restatement (:233-274, :385)."""
+    import sarx
+    from sarx import _ffi, radar
+    from sarx.engine import download_block
+    n_az, n_rg = 7199, 13200
+    ctx = sarx.default_context()
+    args = radar.focus_args()
+    plan = sarx.CsaPlan(ctx, n_az, n_rg, *args)
+    px = n_az * n_rg
+    x, y, z = ctx.alloc(px * 8), ctx.alloc(px * 8), ctx.alloc(px * 8)
+    ctx.fill_noise(x, px, 23313)
+    cols = np.array([0, 1, 31, 32, 33, 63, 64, 6599, 6600, 13167, 13168, 13199])      # incl. both sides of tile edges and the ragged last tile
+    get = lambda buf: np.concatenate([download_block(ctx, buf.ptr, n_rg, 0, n_az, c, 1) for c in cols], axis=1)
+    plan.run_pass(_ffi.PASS_AZ_FFT_PHI1, x, y)
+    xin = get(x)
+    o1 = orc.azimuth_fft_cols(xin, cols, n_rg, *args)
+    g1 = get(y)
+    assert orc.rel_l2(g1, o1) < 5e-6
+    per_row = np.abs(g1 - o1).max(axis=1) / np.abs(o1).max()
+    assert per_row.max() < 1e-4, int(per_row.argmax())          # no single azimuth bin is misplaced
+    np.testing.assert_array_equal(get(x), xin)                  # the source is not modified
+    plan.run_pass(_ffi.PASS_AZ_IFFT, y, z)
+    assert orc.rel_l2(get(z), orc.azimuth_ifft_cols(g1)) < 5e-6
+    for b in (x, y, z):
+        b.release()
+    plan.close()
+
+
+def test_prime_factor_route_equals_chirp_z_route(monkeypatch):
+    import sarx
+    from sarx import radar
+    n_az, n_rg = 7199, 13200
+    ctx = sarx.default_context()
+    args = radar.focus_args()
+    px = n_az * n_rg
+    d_in, d_a, d_b = ctx.alloc(px * 8), ctx.alloc(px * 8), ctx.alloc(px * 8)
+    ctx.fill_noise(d_in, px, 99)
+    pfa = sarx.CsaPlan(ctx, n_az, n_rg, *args)
+    monkeypatch.setenv("SARX_AZ_PFA", "0")
+    czt = sarx.CsaPlan(ctx, n_az, n_rg, *args)
+    monkeypatch.delenv("SARX_AZ_PFA")
+    pfa.focus_dev(d_in, d_a)
+    czt.focus_dev(d_in, d_b)
+    a, b = d_a.download(np.complex64, (n_az, n_rg)), d_b.download(np.complex64, (n_az, n_rg))
+    assert orc.rel_l2(a, b) < 1e-5
+    for buf in (d_in, d_a, d_b):
+        buf.release()
+    pfa.close()
+    czt.close()

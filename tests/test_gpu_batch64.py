@@ -80,6 +80,12 @@ def test_magnitude_stack_slot_is_full_resolution_channel_1():
     for f in (0, 4):
         np.testing.assert_array_equal(st[f], _independent_slot(sarx, ctx, n, f, "magnitude"))
     b.close()
+    # echoes refilled frame by frame inside run() instead of resident per frame: the same stack
+    b2 = TwoChannelBatch(ctx, n, frames, stack="magnitude", resident=False)
+    b2.run()
+    ctx.sync()
+    np.testing.assert_array_equal(b2.stack(), st)
+    b2.close()
 
 
 def _free_port():

@@ -25,6 +25,7 @@ def main():
     from sarx.batch import TwoChannelBatch
     ctx = sarx.Context(0)
     b = TwoChannelBatch(ctx, a.size, a.frames, stack=a.stack)
+    b.prepare()
     b.run()
     ctx.sync()
     t0 = time.perf_counter()
