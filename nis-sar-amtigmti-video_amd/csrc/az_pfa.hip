@@ -17,6 +17,7 @@
 // the bytes in three launches.
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <vector>
 
 #include "csa_kernels.h"
@@ -30,40 +31,51 @@ constexpr int N = 7199, N1 = 23, P = 313, L = 312, RA = 24, RB = 13;
 static_assert(N1 * P == N && RA * RB == L, "factorisation");
 }  // namespace pfa
 
-// 313-point DFTs along rows n = (313 n1 + 23 n2) mod 7199 of a.in, column tile of W samples; result rows n1*313 + k2 of a.u
+// 313-point DFTs along rows n = (313 n1 + 23 n2) mod 7199 of a.in, column tile of W samples; result rows n1*313 + k2 of a.u.
+// One (n1, column tile) per workgroup.  Row addresses are 32-bit byte offsets (the image is < 4 GB): n1 * (313 rows) + a
+// per-q table entry kept in LDS, wrapped at 7199 rows, added to a uniform base pointer.
+// Time budget at 7199 x 13200 (ablation builds, profiles/r02_pfa_ablation.txt): loads + exchanges + stores alone 0.31 ms
+// (5.0 TB/s), arithmetic alone 0.20 ms, together 0.46 ms - with one 768-thread workgroup per CU (78 KiB image, 101 VGPRs)
+// the two do not overlap.  Tried and dropped: 13 threads per column with two butterflies each so that two 416-thread
+// workgroups fit a CU (0.72 ms: the serial work per thread doubles), 16-column tiles (two workgroups per CU, 0.46 ms),
+// prefetching the next n1's rows into a second register set (168 VGPRs + 292 B of scratch per lane).
 template <int W>
 __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
     using namespace pfa;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);                   // [312][W]
-    int* s_gpow = reinterpret_cast<int*>(lds + (size_t)L * W);   // g^q mod 313
-    int* s_ginv = s_gpow + L;                                    // g^-m mod 313
-    const int c = threadIdx.x % W, j = threadIdx.x / W;          // j in [0, 24)
-    const int col = blockIdx.x * W + c, n1 = blockIdx.y;
-    const bool live = col < a.in_cols;
-    const int base1 = P * n1;
-    for (int i = threadIdx.x; i < L; i += RA * W) { s_gpow[i] = a.gpow[i]; s_ginv[i] = a.ginv[i]; }
+    unsigned* tin = reinterpret_cast<unsigned*>(lds + (size_t)L * W);   // 23 g^q rows of the source, in bytes
+    unsigned* tout = tin + L;                                            // g^-m rows of the intermediate, in bytes
+    const unsigned c = threadIdx.x % W, j = threadIdx.x / W;     // j in [0, 24)
+    const unsigned col = blockIdx.x * W + c, n1 = blockIdx.y;
+    const bool live = (int)col < a.in_cols;
+    const unsigned colb = col * (unsigned)sizeof(cf);
+    for (int i = threadIdx.x; i < L; i += RA * W) { tin[i] = a.offin[i]; tout[i] = a.offu[i]; }
     __syncthreads();
+    const char* __restrict__ src = reinterpret_cast<const char*>(a.in);
+    char* __restrict__ dst = reinterpret_cast<char*>(a.u);
+    const unsigned wrap = (unsigned)N * (a.off0in / (unsigned)P);         // bytes of 7199 source rows
 
     cf v[RA];
     cf a0 = make_float2(0.f, 0.f), y0 = a0;
     // forward FFT_312, stage 1: radix 24 on a'[j + 13 r], butterflies j < 13, straight from HBM
     if (j < RB) {
+        const unsigned b = n1 * a.off0in;
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            int row = base1 + N1 * s_gpow[j + RB * r];
-            if (row >= N) row -= N;
-            v[r] = live ? a.in[(size_t)row * a.in_ld + col] : make_float2(0.f, 0.f);
+            unsigned o = b + tin[j + RB * r];
+            if (o >= wrap) o -= wrap;
+            v[r] = live ? *reinterpret_cast<const cf*>(src + (o + colb)) : make_float2(0.f, 0.f);
         }
-        if (j == 0 && live) a0 = a.in[(size_t)base1 * a.in_ld + col];          // n2 = 0
+        if (j == 0 && live) a0 = *reinterpret_cast<const cf*>(src + (b + colb));          // n2 = 0: row 313 n1
         mix::dft_any<RA, false>(v);
 #pragma unroll
-        for (int r = 0; r < RA; ++r) lds[(size_t)(j * RA + r) * W + c] = v[r];
+        for (int r = 0; r < RA; ++r) lds[(j * RA + r) * W + c] = v[r];
     }
     __syncthreads();
     // stage 2: radix 13 on y[j + 24 r], twiddle W_312^(j r); thread j ends with spectrum bins j + 24 r
 #pragma unroll
-    for (int r = 0; r < RB; ++r) v[r] = lds[(size_t)(j + RA * r) * W + c];
+    for (int r = 0; r < RB; ++r) v[r] = lds[(j + RA * r) * W + c];
     mix::apply_powers<RB>(v, cis_frac(-(float)j * (1.0f / (float)L)));
     mix::dft_any<RB, false>(v);
     // times the spectrum of w' (carries the 1/312 of the convolution); the DC bin also gives y[0] and takes a[0]
@@ -75,18 +87,19 @@ __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
     mix::dft_any<RB, true>(v);
     __syncthreads();                                             // stage 2's reads of the image are finished
 #pragma unroll
-    for (int r = 0; r < RB; ++r) lds[(size_t)(j * RB + r) * W + c] = v[r];
+    for (int r = 0; r < RB; ++r) lds[(j * RB + r) * W + c] = v[r];
     __syncthreads();
     // stage 2: radix 24 on z[j + 13 r], twiddle W_312^(-j r), butterflies j < 13; outputs m = j + 13 r go to k2 = g^-m
     if (j < RB) {
 #pragma unroll
-        for (int r = 0; r < RA; ++r) v[r] = lds[(size_t)(j + RB * r) * W + c];
+        for (int r = 0; r < RA; ++r) v[r] = lds[(j + RB * r) * W + c];
         mix::apply_powers<RA>(v, cis_frac((float)j * (1.0f / (float)L)));
         mix::dft_any<RA, true>(v);
-        if (col < a.u_cols) {
+        if ((int)col < a.u_cols) {
+            const unsigned b = n1 * a.off0u + colb;
 #pragma unroll
-            for (int r = 0; r < RA; ++r) a.u[(size_t)(base1 + s_ginv[j + RB * r]) * a.u_ld + col] = v[r];
-            if (j == 0) a.u[(size_t)base1 * a.u_ld + col] = y0;
+            for (int r = 0; r < RA; ++r) *reinterpret_cast<cf*>(dst + (b + tout[j + RB * r])) = v[r];
+            if (j == 0) *reinterpret_cast<cf*>(dst + b) = y0;
         }
     }
 }
@@ -96,22 +109,28 @@ __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
 template <bool INV, int EPI>
 __global__ __launch_bounds__(256) void pfa_dft23_kernel(PfaArgs a) {
     using namespace pfa;
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int k2 = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (col >= a.out_cols || k2 >= P) return;
+    const unsigned col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const unsigned k2 = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if ((int)col >= a.out_cols || k2 >= (unsigned)P) return;
+    const unsigned colb = col * (unsigned)sizeof(cf);
+    const char* __restrict__ src = reinterpret_cast<const char*>(a.u);
+    char* __restrict__ dst = reinterpret_cast<char*>(a.out);
     cf v[N1];
+    unsigned o = k2 * a.pitch_u + colb;                          // row n1*313 + k2: byte offset advances by 313 rows
 #pragma unroll
-    for (int n1 = 0; n1 < N1; ++n1) v[n1] = a.u[(size_t)(n1 * P + k2) * a.u_ld + col];
+    for (int n1 = 0; n1 < N1; ++n1) { v[n1] = *reinterpret_cast<const cf*>(src + o); o += a.off0u; }
     mix::dft_any<N1, INV>(v);
-    int row = (int)(((long long)a.c2k * k2) % N);
+    unsigned row = (unsigned)(((unsigned long long)a.c2k * k2) % N);
+    unsigned oo = row * a.pitch_out + colb;
+    const unsigned step = (unsigned)a.c1k * a.pitch_out, wrap = (unsigned)N * a.pitch_out;
 #pragma unroll
     for (int k1 = 0; k1 < N1; ++k1) {
         cf x = v[k1];
-        if constexpr (EPI == 1) x = cmul(x, phi1(col, a.c1[row], a.dt, a.t_start));
+        if constexpr (EPI == 1) x = cmul(x, phi1((int)col, a.c1[row], a.dt, a.t_start));
         else if constexpr (EPI == 2) { x.x *= a.scale; x.y *= a.scale; }
-        a.out[(size_t)row * a.out_ld + col] = x;
-        row += a.c1k;
-        if (row >= N) row -= N;
+        *reinterpret_cast<cf*>(dst + oo) = x;
+        row += a.c1k; oo += step;
+        if (row >= (unsigned)N) { row -= N; oo -= wrap; }
     }
 }
 
@@ -128,15 +147,17 @@ static int inv_mod(int a, int m) { return pow_mod(a, m - 2, m); }     // m prime
 
 struct AzPfa {
     int *gpow = nullptr, *ginv = nullptr;
+    unsigned *offin = nullptr, *offu = nullptr;   // [312] byte offsets: 23 g^q rows of the source, g^-m rows of the intermediate
+    size_t in_ld = 0, u_ld = 0, out_ld = 0;       // leading dimensions (elements) the tables were built for
     cf *bspec_f = nullptr, *bspec_i = nullptr;
     int c1k = 0, c2k = 0;
 };
 void az_pfa_destroy(AzPfa* z) {
     if (!z) return;
-    hipFree(z->gpow); hipFree(z->ginv); hipFree(z->bspec_f); hipFree(z->bspec_i);
+    hipFree(z->gpow); hipFree(z->ginv); hipFree(z->offin); hipFree(z->offu); hipFree(z->bspec_f); hipFree(z->bspec_i);
     delete z;
 }
-AzPfa* az_pfa_create(hipError_t* err) {
+AzPfa* az_pfa_create(size_t in_ld, size_t u_ld, size_t out_ld, hipError_t* err) {
     using namespace pfa;
     AzPfa* z = new AzPfa();
     int g = 2;                                                   // smallest primitive root mod 313: order exactly 312 = 2^3 * 3 * 13
@@ -168,6 +189,20 @@ AzPfa* az_pfa_create(hipError_t* err) {
         e = hipMalloc(d, bytes);
         if (e == hipSuccess) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
     };
+    // byte offsets fit 32 bits: the images are [7199 x ld] complex64 with ld <= 32768 + 31
+    if (2ull * N * (in_ld > u_ld ? (in_ld > out_ld ? in_ld : out_ld) : (u_ld > out_ld ? u_ld : out_ld)) * sizeof(cf) >= (1ull << 32)) {
+        if (err) *err = hipErrorInvalidValue;
+        delete z;
+        return nullptr;
+    }
+    z->in_ld = in_ld; z->u_ld = u_ld; z->out_ld = out_ld;
+    std::vector<unsigned> offin(L), offu(L);                   // n1 enters in the kernel as n1 * (313 rows), wrapped at 7199 rows
+    for (int q = 0; q < L; ++q) {
+        offin[q] = (unsigned)((size_t)(N1 * gpow[q]) * in_ld * sizeof(cf));
+        offu[q] = (unsigned)((size_t)ginv[q] * u_ld * sizeof(cf));
+    }
+    up(offin.data(), offin.size() * sizeof(unsigned), (void**)&z->offin);
+    up(offu.data(), offu.size() * sizeof(unsigned), (void**)&z->offu);
     up(gpow.data(), L * sizeof(int), (void**)&z->gpow);
     up(ginv.data(), L * sizeof(int), (void**)&z->ginv);
     up(bf.data(), L * sizeof(cf), (void**)&z->bspec_f);
@@ -188,9 +223,12 @@ hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, in
     a.in = src; a.in_ld = src_ld; a.in_cols = src_cols;
     a.u = u; a.u_ld = u_ld; a.u_cols = (int)(u_ld < (size_t)dst_cols ? u_ld : (size_t)dst_cols);
     a.out = dst; a.out_ld = dst_ld; a.out_cols = dst_cols;
-    a.gpow = z->gpow; a.ginv = z->ginv; a.bspec = inv ? z->bspec_i : z->bspec_f;
+    a.gpow = z->gpow; a.ginv = z->ginv; a.offin = z->offin; a.offu = z->offu; a.bspec = inv ? z->bspec_i : z->bspec_f;
     a.c1 = c1; a.dt = dt; a.t_start = t_start; a.scale = scale; a.c1k = z->c1k; a.c2k = z->c2k;
-    const size_t lds = (size_t)L * W * sizeof(cf) + 2 * L * sizeof(int);
+    if (src_ld != z->in_ld || u_ld != z->u_ld || dst_ld != z->out_ld) return hipErrorInvalidValue;   // tables are per pitch
+    a.off0in = (unsigned)(P * src_ld * sizeof(cf)); a.off0u = (unsigned)(P * u_ld * sizeof(cf));
+    a.pitch_u = (unsigned)(u_ld * sizeof(cf)); a.pitch_out = (unsigned)(dst_ld * sizeof(cf));
+    const size_t lds = (size_t)L * W * sizeof(cf) + 2 * L * sizeof(unsigned);     // image + this n1's two offset tables
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfa_rader313_kernel<W>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -98,6 +98,9 @@ struct PfaArgs {
     float2* u; size_t u_ld; int u_cols;                // intermediate, rows n1*313 + k2
     float2* out; size_t out_ld; int out_cols;         // dense destination, rows in natural bin / pulse order
     const int* gpow; const int* ginv;                  // g^q, g^-m mod 313 (312 each)
+    const unsigned* offin; const unsigned* offu;       // [312] byte offsets of 23 g^q source rows / g^-m intermediate rows
+    unsigned off0in, off0u;                            // bytes of 313 rows of the source / intermediate
+    unsigned pitch_u, pitch_out;                       // bytes of one row of the intermediate / destination
     const float2* bspec;                               // spectrum of the Rader kernel w' / 312, for the transform's sign
     const double2* c1; double dt, t_start;             // Phi_1 epilogue
     float scale;                                       // inverse: 1/7199
@@ -105,7 +108,8 @@ struct PfaArgs {
 };
 struct AzPfa;
 bool az_pfa_supported(int n_az);
-AzPfa* az_pfa_create(hipError_t* err);
+// tables are built for fixed leading dimensions (elements) of the source, the intermediate and the destination
+AzPfa* az_pfa_create(size_t in_ld, size_t u_ld, size_t out_ld, hipError_t* err);
 void az_pfa_destroy(AzPfa* z);
 // epi: 0 none, 1 times Phi_1 (forward), 2 times scale (inverse).  src may equal dst; u is a [7199 x u_ld] work array
 hipError_t az_pfa_run(const AzPfa* z, bool inv, const float2* src, size_t src_ld, int src_cols, float2* u, size_t u_ld,

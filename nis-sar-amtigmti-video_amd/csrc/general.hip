@@ -806,7 +806,7 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
     const char* pv = getenv("SARX_AZ_PFA");               // SARX_AZ_PFA=0 keeps the chirp-z azimuth route (A/B measurements)
     if (g->rg_mixed && az_pfa_supported(n_az) && !(pv && atoi(pv) == 0)) {
         hipError_t pe = hipSuccess;
-        g->pfa = az_pfa_create(&pe);
+        g->pfa = az_pfa_create((size_t)n_rg, (size_t)g->ldc, (size_t)n_rg, &pe);
         if (!g->pfa) { err = std::string("prime-factor tables: ") + hipGetErrorString(pe); general_csa_destroy(g); return nullptr; }
     }
     auto bail = [&](const char* what, hipError_t e) {
