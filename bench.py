@@ -142,6 +142,15 @@ def main():
             sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, rank 0's JSON: gloo and RCCL print banners to the C-level stdout, so everything a
+    # rank writes to fd 1 goes to stderr from here on and the JSON line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -157,7 +166,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks}), flush=True)
+            emit({"dry_run": True, "n_gpus": world, "ranks": ranks})
         return
 
     import numpy as np
@@ -334,7 +343,7 @@ def main():
             mt = min(os.cpu_count() or 1, 32)
             if mt > 1:                              # the all-core figure on the real frame next to the reference-style single thread
                 line["cpu_baseline_threads"] = cpu_baseline(n, workers=mt, scaled=False)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

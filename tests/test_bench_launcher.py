@@ -22,7 +22,8 @@ def test_bare_gpus_n_spawns_n_ranks():
     r = _run(["--gpus", "2", "--dry-run"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert "spawning 2 ranks" in r.stderr
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout       # gloo / RCCL banners must not reach stdout: ONE JSON line
+    line = json.loads(r.stdout)
     assert line["dry_run"] and line["n_gpus"] == 2
     assert sorted(x["rank"] for x in line["ranks"]) == [0, 1]
     assert sorted(x["local_rank"] for x in line["ranks"]) == [0, 1]
