@@ -146,7 +146,6 @@ static int pow_mod(long long b, long long e, long long m) {
 static int inv_mod(int a, int m) { return pow_mod(a, m - 2, m); }     // m prime
 
 struct AzPfa {
-    int *gpow = nullptr, *ginv = nullptr;
     unsigned *offin = nullptr, *offu = nullptr;   // [312] byte offsets: 23 g^q rows of the source, g^-m rows of the intermediate
     size_t in_ld = 0, u_ld = 0, out_ld = 0;       // leading dimensions (elements) the tables were built for
     cf *bspec_f = nullptr, *bspec_i = nullptr;
@@ -154,7 +153,7 @@ struct AzPfa {
 };
 void az_pfa_destroy(AzPfa* z) {
     if (!z) return;
-    hipFree(z->gpow); hipFree(z->ginv); hipFree(z->offin); hipFree(z->offu); hipFree(z->bspec_f); hipFree(z->bspec_i);
+    hipFree(z->offin); hipFree(z->offu); hipFree(z->bspec_f); hipFree(z->bspec_i);
     delete z;
 }
 AzPfa* az_pfa_create(size_t in_ld, size_t u_ld, size_t out_ld, hipError_t* err) {
@@ -203,8 +202,6 @@ AzPfa* az_pfa_create(size_t in_ld, size_t u_ld, size_t out_ld, hipError_t* err) 
     }
     up(offin.data(), offin.size() * sizeof(unsigned), (void**)&z->offin);
     up(offu.data(), offu.size() * sizeof(unsigned), (void**)&z->offu);
-    up(gpow.data(), L * sizeof(int), (void**)&z->gpow);
-    up(ginv.data(), L * sizeof(int), (void**)&z->ginv);
     up(bf.data(), L * sizeof(cf), (void**)&z->bspec_f);
     up(bi.data(), L * sizeof(cf), (void**)&z->bspec_i);
     if (err) *err = e;
@@ -223,7 +220,7 @@ hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, in
     a.in = src; a.in_ld = src_ld; a.in_cols = src_cols;
     a.u = u; a.u_ld = u_ld; a.u_cols = (int)(u_ld < (size_t)dst_cols ? u_ld : (size_t)dst_cols);
     a.out = dst; a.out_ld = dst_ld; a.out_cols = dst_cols;
-    a.gpow = z->gpow; a.ginv = z->ginv; a.offin = z->offin; a.offu = z->offu; a.bspec = inv ? z->bspec_i : z->bspec_f;
+    a.offin = z->offin; a.offu = z->offu; a.bspec = inv ? z->bspec_i : z->bspec_f;
     a.c1 = c1; a.dt = dt; a.t_start = t_start; a.scale = scale; a.c1k = z->c1k; a.c2k = z->c2k;
     if (src_ld != z->in_ld || u_ld != z->u_ld || dst_ld != z->out_ld) return hipErrorInvalidValue;   // tables are per pitch
     a.off0in = (unsigned)(P * src_ld * sizeof(cf)); a.off0u = (unsigned)(P * u_ld * sizeof(cf));

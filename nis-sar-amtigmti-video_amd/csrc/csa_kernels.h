@@ -97,7 +97,6 @@ struct PfaArgs {
     const float2* in; size_t in_ld; int in_cols;      // dense source [7199 x in_cols]
     float2* u; size_t u_ld; int u_cols;                // intermediate, rows n1*313 + k2
     float2* out; size_t out_ld; int out_cols;         // dense destination, rows in natural bin / pulse order
-    const int* gpow; const int* ginv;                  // g^q, g^-m mod 313 (312 each)
     const unsigned* offin; const unsigned* offu;       // [312] byte offsets of 23 g^q source rows / g^-m intermediate rows
     unsigned off0in, off0u;                            // bytes of 313 rows of the source / intermediate
     unsigned pitch_u, pitch_out;                       // bytes of one row of the intermediate / destination
