@@ -102,9 +102,12 @@ int sarx_event_record(sarx_ctx* ctx, int slot);
 int sarx_event_elapsed_ms(sarx_ctx* ctx, int slot_start, int slot_stop, float* out_ms);
 
 /* ---- CSA focus: replaces sar_focus_csa (sar_ati_dcpa_sim_csa.py:202-396) -- */
-/* n_az, n_rg in [2, 32768].  Powers of two >= 16 run the tuned kernels; any other size (the
- * reference's native 7199 x 13200, :47,111,402) runs chirp-z transforms over them (a non-power-of-two
- * n_az must be <= 16384; range lines beyond 16384 samples run as 128 x 256 / 256 x 256 split transforms).  Unsupported sizes fail with SARX_ERR_UNSUPPORTED, never silently. */
+/* n_az, n_rg in [2, 32768].  Powers of two >= 16 run the tuned kernels; the reference's native 7199 x 13200 (:47,111,402)
+ * runs direct transforms (mixed-radix 24 x 22 x 25 range lines, prime-factor 23 x 313 azimuth transforms); any other size runs
+ * chirp-z transforms over the power-of-two kernels (a non-power-of-two n_az must be <= 16384; range lines beyond 16384 samples
+ * run as 128 x 256 / 256 x 256 split transforms).  Unsupported sizes fail with SARX_ERR_UNSUPPORTED, never silently.
+ * Environment switches read at plan creation, for A/B measurements only: SARX_RANGE_MIXED=0, SARX_AZ_PFA=0 (chirp-z routes at
+ * the native size), SARX_SLAB_MIB=<MiB> (tile-grouped middle section of the power-of-two focus; measured slower, off by default). */
 int sarx_csa_plan_create(sarx_ctx* ctx, int n_az, int n_rg, const sarx_radar_params* params,
                          unsigned flags, sarx_plan** out_plan);
 int sarx_csa_plan_destroy(sarx_plan* plan);
@@ -116,7 +119,8 @@ int sarx_csa_focus_host(sarx_plan* plan, const void* phist_host, void* image_hos
 /* device in / device out, asynchronous on the ctx stream.  d_phist is not modified.
  * d_image must not alias d_phist. */
 int sarx_csa_focus_dev(sarx_plan* plan, const void* d_phist, void* d_image);
-/* one pass, device to device (d_out may equal d_in only for the range passes) */
+/* one pass, device to device (d_out may equal d_in only for the range passes).  Power-of-two plans: every pass;
+ * 7199 x 13200 plans: every pass; other any-size plans with n_rg = 13200: the range passes; otherwise SARX_ERR_UNSUPPORTED */
 int sarx_csa_pass(sarx_plan* plan, int pass_id, const void* d_in, void* d_out);
 /* profiling hook: sarx_csa_focus_dev records ctx event slots around its range pass(es)
  * (the roofline kernel); pass -1, -1 to switch off */
