@@ -815,7 +815,8 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
         return (GeneralCsa*)nullptr;
     };
     hipError_t e;
-    if ((e = axis_init(g->az, n_az, 32768, 32768, false)) != hipSuccess) {
+    if (g->pfa) { g->az.n = n_az; g->az.m = n_az; }       // no chirp-z tables along azimuth either
+    else if ((e = axis_init(g->az, n_az, 32768, 32768, false)) != hipSuccess) {
         if (e == hipErrorInvalidValue) { err = "a non-power-of-two n_az must be <= 16384 (chirp-z length 32768)"; general_csa_destroy(g); return nullptr; }
         return bail("azimuth tables", e);
     }
@@ -844,9 +845,11 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
     const size_t cols_work = (size_t)g->az.m * (size_t)g->ldc;
     g->work_elems = rows_work > cols_work ? rows_work : cols_work;
     if ((e = hipMalloc(&g->data, (size_t)n_az * n_rg * sizeof(cf))) != hipSuccess) return bail("hipMalloc image", e);
+    // the prime-factor route needs ONE [n_az x ldc] intermediate; the chirp-z routes two [m_az x ldc] / [n_az x m_rg] work arrays
+    const int n_work = g->pfa ? 1 : 2;
     if ((e = hipMalloc(&g->work_a, g->work_elems * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
-    if ((e = hipMalloc(&g->work_b, g->work_elems * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
-    g->bytes = ((size_t)n_az * n_rg + 2 * g->work_elems) * sizeof(cf) + 3 * tb;
+    if (n_work == 2 && (e = hipMalloc(&g->work_b, g->work_elems * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
+    g->bytes = ((size_t)n_az * n_rg + (size_t)n_work * g->work_elems) * sizeof(cf) + 3 * tb;
     // range FFT . Phi_2 . IFFT as one convolution: per-row kernel spectra (SARX_GENERAL_KTAB=0 keeps the two chirp-z transforms)
     const char* ev = getenv("SARX_GENERAL_KTAB");
     if (csa_tables && !g->rg.direct && !(ev && atoi(ev) == 0)) {
