@@ -207,17 +207,21 @@ def main():
             plan.mark_range(2 * s, 2 * s + 1)
         else:
             plan.mark_range(-1, -1)
-        plan.focus_dev(d_in, d_img)
         if d_recv is None:
+            plan.focus_dev(d_in, d_img)
             return
+        # the frame's stack slot (16x16 multilook) comes out of the focus itself: row-wise partials from the last azimuth
+        # launch + a small finish launch (sarx_csa_plan_set_look_slot), +0.05 ms instead of re-reading the image
         block = d_recv.ptr + (s & 1) * slot_bytes * world
         mine = block + rank * slot_bytes
         if use_rccl:
-            ctx.comm_fence_compute()                      # block (s&1) was last read/written by the gather of step s-2
-            ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, mine, n, n, LOOKS)
+            ctx.lib.sarx_comm_wait_mark(ctx.h, s & 1)     # block (s&1) was last read/written by the gather of step s-2 (step s-1's still overlaps)
+        plan.set_look_slot(LOOKS, mine)
+        plan.focus_dev(d_in, d_img)
+        if use_rccl:
             ctx.lib.sarx_allgather_dev(ctx.h, mine, block, slot_bytes)
+            ctx.lib.sarx_comm_mark(ctx.h, s & 1)
         else:
-            ctx.lib.sarx_multilook_dev(ctx.h, d_img.ptr, mine, n, n, LOOKS)
             if host_comm is not None:
                 slot = np.empty((n // LOOKS, n // LOOKS), dtype=np.float32)
                 _ffi.check(ctx.lib.sarx_memcpy_d2h(ctx.h, slot.ctypes.data, mine, slot_bytes), ctx.h)
@@ -298,7 +302,7 @@ def main():
                        "frames_per_step_per_gpu": 1, "range_passes": "fused 2+3" if not a.unfused else "separate",
                        "image_layout": "[n_az x n_rg]; img.T returned as a view like the reference",
                        "parallelism": f"frames sharded 1/GPU x{world}" +
-                                      (f"; 16x16 multilook + {collective} per step" if collective else "")},
+                                      (f"; 16x16 multilook slot fused into the focus + {collective} per step" if collective else "")},
             "roofline": {"bound": "hbm", "kernel": ("range_fused_wl_kernel (FFT.Phi2.IFFT.Phi3, one HBM round trip)"
                                                     if (not a.unfused and n == 16384) else
                                                     "range_pass_kernel<fused>" if not a.unfused else

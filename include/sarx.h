@@ -125,6 +125,12 @@ int sarx_csa_pass(sarx_plan* plan, int pass_id, const void* d_in, void* d_out);
 /* profiling hook: sarx_csa_focus_dev records ctx event slots around its range pass(es)
  * (the roofline kernel); pass -1, -1 to switch off */
 int sarx_csa_plan_mark_range(sarx_plan* plan, int slot_start, int slot_stop);
+/* VideoSAR stack slot fused into the focus: while d_slot is set, every sarx_csa_focus_dev of this plan also writes
+ * d_slot[(n_az/looks) x (n_rg/looks)] fp32 = mean of |image|^2 over looks x looks blocks (what sarx_multilook_dev computes from the
+ * finished image, sar_batch_sim.py:322's display stack) - the last azimuth launch emits row-wise partial sums and a small launch
+ * finishes them, so the 2 GiB image is not read again.  looks: a power of two <= 32 dividing both extents; power-of-two plans
+ * only; the slot is [n_az/looks x n_rg/looks] whatever the image layout.  d_slot = NULL switches it off.  Bitwise reproducible. */
+int sarx_csa_plan_set_look_slot(sarx_plan* plan, int looks, float* d_slot);
 /* bytes of HBM scratch the plan holds (two ping-pong images + tables) */
 int sarx_csa_plan_bytes(const sarx_plan* plan, uint64_t* out_bytes);
 
@@ -278,6 +284,12 @@ int sarx_comm_sync(sarx_ctx* ctx);
 /* device-side only: later work on the compute stream waits for every gather enqueued so far
  * (call before overwriting a send buffer that an earlier sarx_allgather_dev may still read) */
 int sarx_comm_fence_compute(sarx_ctx* ctx);
+/* finer than the fence: sarx_comm_mark records "every gather enqueued so far is finished" in one of four slots on the comm stream;
+ * sarx_comm_wait_mark makes later compute-stream work wait (on the device) for that slot's mark (no-op if never recorded).  A
+ * double-buffered gather target marks slot (s & 1) after the gather of step s and waits for it before step s + 2 writes the
+ * buffer again, so the gather of step s + 1 still overlaps the compute of step s + 2. */
+int sarx_comm_mark(sarx_ctx* ctx, int slot);
+int sarx_comm_wait_mark(sarx_ctx* ctx, int slot);
 int sarx_comm_destroy(sarx_ctx* ctx);
 
 #ifdef __cplusplus

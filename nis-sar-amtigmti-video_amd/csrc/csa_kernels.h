@@ -16,7 +16,8 @@ enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_S
                   AZ_EPI_TWIDDLE_ROWSIN = 9,  // TWIDDLE, but input rows >= io_rows are zeros that are not read (chirp-z padding)
                   AZ_EPI_SCALE_ROWSOUT = 10,
                   AZ_EPI_CROPOUT_PHI1 = 11,
-                  AZ_EPI_CROPOUT_MAG = 12 };    // CROPOUT, but the magnitude goes to out_mag (fp32) instead of the complex value to out   // CROPOUT, then * Phi_1(output row, col): the forward azimuth chirp-z ends in the CSA's first phase  // SCALE, but output rows >= io_rows are not written (only the cropped part is used)       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
+                  AZ_EPI_CROPOUT_MAG = 12,
+                  AZ_EPI_SCALE_LOOK = 13 };     // SCALE, and the row's sums of |x|^2 over `look` consecutive columns go to look_part (VideoSAR stack slot fused into the focus)    // CROPOUT, but the magnitude goes to out_mag (fp32) instead of the complex value to out   // CROPOUT, then * Phi_1(output row, col): the forward azimuth chirp-z ends in the CSA's first phase  // SCALE, but output rows >= io_rows are not written (only the cropped part is used)       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
 
 struct RangeArgs {
     const float2* in;
@@ -52,6 +53,8 @@ struct AzArgs {
     int io_shift_in;      // TWIDDLE_PADIN: sequence element r is source row (r + io_shift_in) mod io_rows (fftshift bookkeeping)
     int io_shift_out;     // CROPOUT*: sequence element r goes to destination row (r + io_shift_out) mod io_rows
     float* out_mag;       // CROPOUT_MAG: [io_rows x io_cols] fp32 magnitudes (leading dimension io_ld)
+    float* look_part;     // SCALE_LOOK: [n_az x n_rg/look] row-wise partial sums of |x|^2 over `look` columns (a power of two <= tile width)
+    int look;
     int valid_len;        // TWCOL / PROCOL (split lines): only the first valid_len samples of a line are read (rest = 0) / written; 0 = all
     double dt, t_start;
     float scale;          // 1/n_az for the inverse's last step
@@ -143,6 +146,8 @@ hipError_t launch_mask_phase_frac(const float* phase, const float* mag, size_t n
 hipError_t launch_magnitude(const float2* in, float* out, size_t n, hipStream_t st);
 hipError_t launch_corner_turn(const float2* in, float2* out, int rows, int cols, hipStream_t st);
 hipError_t launch_multilook(const float2* in, float* out, int rows, int cols, int looks, hipStream_t st);
+// out[R][C] = (sum over r < looks of part[(looks R + r) * cols + C]) / looks^2: second half of the multilook fused into the focus
+hipError_t launch_look_finish(const float* part, float* out, int out_rows, int cols, int looks, hipStream_t st);
 hipError_t launch_fill_noise(float2* buf, size_t n, uint64_t seed, hipStream_t st);
 
 hipError_t launch_ocean_noise(float2* buf, size_t n, float sigma, float clutter_power, float nu, uint64_t seed, hipStream_t st);

@@ -253,6 +253,13 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
 #endif
             } else if constexpr (EPI == AZ_EPI_PHI1) {
                 x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
+            } else if constexpr (EPI == AZ_EPI_SCALE_LOOK) {
+                x.x *= a.scale; x.y *= a.scale;
+                // |x|^2 summed over the `look` consecutive columns of this row (consecutive lanes): fixed xor tree, bitwise
+                // reproducible; the lane of the group's first column stores the row-wise partial
+                float pw = fmaf(x.x, x.x, x.y * x.y);
+                for (int off = 1; off < a.look; off <<= 1) pw += __shfl_xor(pw, off, 64);
+                if ((c & (a.look - 1)) == 0) a.look_part[rowo * (size_t)(a.n_rg / a.look) + col / a.look] = pw;
             } else if constexpr (EPI == AZ_EPI_SCALE || EPI == AZ_EPI_PROCOL) {
                 if constexpr (EPI == AZ_EPI_PROCOL) {      // only the cropped part of the line is wanted
                     if (a.valid_len && m * a.n_rg + col >= a.valid_len) continue;
@@ -305,6 +312,7 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_NONE: return launch_az_one<R, W, true, AZ_EPI_NONE>(a, nq, st);
             case AZ_EPI_TWIDDLE: return launch_az_one<R, W, true, AZ_EPI_TWIDDLE>(a, nq, st);
             case AZ_EPI_SCALE: return launch_az_one<R, W, true, AZ_EPI_SCALE>(a, nq, st);
+            case AZ_EPI_SCALE_LOOK: return launch_az_one<R, W, true, AZ_EPI_SCALE_LOOK>(a, nq, st);
             case AZ_EPI_PROCOL: return launch_az_one<R, W, true, AZ_EPI_PROCOL>(a, nq, st);
             case AZ_EPI_CROPOUT: return launch_az_one<R, W, true, AZ_EPI_CROPOUT>(a, nq, st);
             case AZ_EPI_SCALE_ROWSOUT: return launch_az_one<R, W, true, AZ_EPI_SCALE_ROWSOUT>(a, nq, st);

@@ -285,6 +285,23 @@ hipError_t launch_multilook(const cf* in, float* out, int rows, int cols, int lo
     return hipGetLastError();
 }
 
+// second half of the multilook fused into the focus (AZ_EPI_SCALE_LOOK wrote row-wise sums over `looks` columns): sum the
+// `looks` rows of each block in a fixed order and divide by looks^2.  Reads n_az x n_rg/looks floats (64 MiB at 16384^2 / 16
+// looks) instead of the 2 GiB image.
+__global__ __launch_bounds__(256) void look_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int out_rows,
+                                                          int cols, int L) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= out_rows) return;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += part[(size_t)(r * L + l) * cols + c];
+    out[(size_t)r * cols + c] = s / (float)(L * L);
+}
+hipError_t launch_look_finish(const float* part, float* out, int out_rows, int cols, int looks, hipStream_t st) {
+    dim3 grid((cols + 255) / 256, out_rows);
+    hipLaunchKernelGGL(look_finish_kernel, grid, dim3(256), 0, st, part, out, out_rows, cols, looks);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------
 // counter-based complex Gaussian noise: sample i depends only on (seed, i)
 // ------------------------------------------------------------------------------

@@ -91,6 +91,8 @@ struct sarx_ctx {
     bool ev_set[N_EVENTS] = {};
     hipEvent_t comm_fence = nullptr;
     hipEvent_t comm_done = nullptr;
+    hipEvent_t comm_mark[4] = {};      // sarx_comm_mark / sarx_comm_wait_mark: "gathers enqueued up to here are finished"
+    bool comm_mark_set[4] = {};
     float2* tw_all = nullptr;          // table for size n at offset n: exp(-2 pi i m/n)
     float* ati_part_max = nullptr;     // reduction scratch
     double2* ati_part_sum = nullptr;
@@ -108,6 +110,9 @@ struct sarx_plan {
     sarx_radar_params p{};
     int az_s = 0;          // four-step split: n_az = (n_az/az_s) * az_s; az_s == n_az means single step
     int az_w = 32;         // azimuth tile width (range samples)
+    int look = 0;          // > 0: the last azimuth launch also writes row-wise |x|^2 partials and a finish launch turns them into look_slot
+    float* look_slot = nullptr;   // caller's [n_az/look x n_rg/look] fp32 slot (device)
+    float* look_part = nullptr;   // [n_az x n_rg/look], owned by the plan
     int slab_tiles = 0;    // > 0: slab mode of sarx_csa_focus_dev with this many azimuth tiles per group (SARX_SLAB_MIB)
     double2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr;
     float2* buf_b = nullptr;           // scratch image
@@ -175,6 +180,7 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
     for (int i = 0; i < N_EVENTS; ++i) HIPCHK(nullptr, hipEventCreate(&c->ev[i]));
     HIPCHK(nullptr, hipEventCreateWithFlags(&c->comm_fence, hipEventDisableTiming));
     HIPCHK(nullptr, hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming));
+    for (int i = 0; i < 4; ++i) HIPCHK(nullptr, hipEventCreateWithFlags(&c->comm_mark[i], hipEventDisableTiming));
     // twiddle tables for every power of two up to TW_MAX, fp64-evaluated
     std::vector<float2> tw(2 * TW_MAX);
     tw[0] = tw[1] = make_float2(1.f, 0.f);
@@ -201,6 +207,7 @@ int sarx_destroy(sarx_ctx* c) {
     for (int i = 0; i < N_EVENTS; ++i) hipEventDestroy(c->ev[i]);
     hipEventDestroy(c->comm_fence);
     hipEventDestroy(c->comm_done);
+    for (int i = 0; i < 4; ++i) hipEventDestroy(c->comm_mark[i]);
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->comm_stream);
     delete c;
@@ -375,7 +382,7 @@ int sarx_csa_plan_destroy(sarx_plan* p) {
     hipStreamSynchronize(p->ctx->stream);
     general_csa_destroy(p->gen);
     hipFree(p->c1); hipFree(p->c2); hipFree(p->c3);
-    hipFree(p->buf_a); hipFree(p->buf_b); hipFree(p->h_in); hipFree(p->h_out);
+    hipFree(p->buf_a); hipFree(p->buf_b); hipFree(p->h_in); hipFree(p->h_out); hipFree(p->look_part);
     delete p;
     return SARX_OK;
 }
@@ -384,6 +391,25 @@ int sarx_csa_plan_mark_range(sarx_plan* p, int slot_start, int slot_stop) {
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
     if (slot_start >= N_EVENTS || slot_stop >= N_EVENTS) return fail(p->ctx, SARX_ERR_INVALID, "event slot out of range");
     p->mark_start = slot_start; p->mark_stop = slot_stop;
+    return SARX_OK;
+}
+
+int sarx_csa_plan_set_look_slot(sarx_plan* p, int looks, float* d_slot) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!d_slot) { p->look_slot = nullptr; return SARX_OK; }            // switch off; the partials buffer is kept
+    if (p->gen) return fail(c, SARX_ERR_UNSUPPORTED, "the fused stack slot exists for power-of-two plans only (use sarx_multilook_dev)");
+    if (looks < 1 || (looks & (looks - 1)) || looks > p->az_w || p->n_az % looks || p->n_rg % looks)
+        return fail(c, SARX_ERR_UNSUPPORTED, "looks=%d must be a power of two <= %d dividing n_az=%d and n_rg=%d", looks, p->az_w, p->n_az, p->n_rg);
+    if (p->look_part && p->look != looks) { hipStreamSynchronize(c->stream); hipFree(p->look_part); p->look_part = nullptr; }
+    if (!p->look_part) {
+        const size_t bytes = (size_t)p->n_az * (p->n_rg / looks) * sizeof(float);
+        hipError_t e = hipMalloc(&p->look_part, bytes);
+        if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc look partials: %s", hipGetErrorString(e));
+        p->bytes += bytes;
+    }
+    p->look = looks; p->look_slot = d_slot;
     return SARX_OK;
 }
 
@@ -457,8 +483,17 @@ static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, v
     } else {
         a.tw_r = c->tw_all + S;
         a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
-        HIPCHK(c, launch_az_tile(S, p->az_w, inv, inv ? AZ_EPI_SCALE : AZ_EPI_PHI1, a, nq, c->stream));
+        const bool look = inv && p->look_slot;
+        if (look) { a.look_part = p->look_part; a.look = p->look; }
+        HIPCHK(c, launch_az_tile(S, p->az_w, inv, inv ? (look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, nq, c->stream));
     }
+    return SARX_OK;
+}
+// the finish half of the fused multilook, after the last azimuth launch of a focus
+static int look_finish(sarx_plan* p) {
+    if (!p->look_slot) return SARX_OK;
+    sarx_ctx* c = p->ctx;
+    HIPCHK(c, launch_look_finish(p->look_part, p->look_slot, p->n_az / p->look, p->n_rg / p->look, p->look, c->stream));
     return SARX_OK;
 }
 
@@ -477,7 +512,9 @@ static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out)
         a.in = (const float2*)in; a.out = (float2*)out;
         a.tw_r = c->tw_all + n;
         a.in_q_stride = 0; a.in_m_stride = 1; a.out_q_stride = 0; a.out_m_stride = 1;
-        HIPCHK(c, launch_az_tile(n, p->az_w, inv, inv ? AZ_EPI_SCALE : AZ_EPI_PHI1, a, 1, c->stream));
+        const bool look = inv && p->look_slot;
+        if (look) { a.look_part = p->look_part; a.look = p->look; }
+        HIPCHK(c, launch_az_tile(n, p->az_w, inv, inv ? (look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, 1, c->stream));
         return SARX_OK;
     }
     int rc;
@@ -561,6 +598,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
             if ((rc = az_step(p, true, false, RA, p->buf_b, p->buf_b, q0, nq)) != SARX_OK) return rc;   // inverse step A, stride RA
         }
         if ((rc = az_step(p, true, true, RA, p->buf_b, last, 0, S)) != SARX_OK) return rc;           // inverse step B, whole image
+        if ((rc = look_finish(p)) != SARX_OK) return rc;
         if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
         return SARX_OK;
     }
@@ -584,6 +622,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     } else {
         if ((rc = az_pass(p, true, p->buf_b, p->buf_b, last)) != SARX_OK) return rc;
     }
+    if ((rc = look_finish(p)) != SARX_OK) return rc;
     if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
     return SARX_OK;
 }
@@ -948,6 +987,19 @@ int sarx_comm_fence_compute(sarx_ctx* c) {
     NEED_CTX(c);
     HIPCHK(c, hipEventRecord(c->comm_done, c->comm_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->comm_done, 0));
+    return SARX_OK;
+}
+int sarx_comm_mark(sarx_ctx* c, int slot) {
+    NEED_CTX(c);
+    if (slot < 0 || slot >= 4) return fail(c, SARX_ERR_INVALID, "comm mark slot %d out of range [0,4)", slot);
+    HIPCHK(c, hipEventRecord(c->comm_mark[slot], c->comm_stream));
+    c->comm_mark_set[slot] = true;
+    return SARX_OK;
+}
+int sarx_comm_wait_mark(sarx_ctx* c, int slot) {
+    NEED_CTX(c);
+    if (slot < 0 || slot >= 4) return fail(c, SARX_ERR_INVALID, "comm mark slot %d out of range [0,4)", slot);
+    if (c->comm_mark_set[slot]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->comm_mark[slot], 0));
     return SARX_OK;
 }
 int sarx_comm_destroy(sarx_ctx* c) {

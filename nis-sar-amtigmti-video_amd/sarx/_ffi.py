@@ -74,6 +74,7 @@ SIGNATURES = {
     "sarx_csa_focus_dev": (_i, [_vp, _vp, _vp]),
     "sarx_csa_pass": (_i, [_vp, _i, _vp, _vp]),
     "sarx_csa_plan_mark_range": (_i, [_vp, _i, _i]),
+    "sarx_csa_plan_set_look_slot": (_i, [_vp, _i, _vp]),
     "sarx_csa_plan_bytes": (_i, [_vp, _P(_u64)]),
     "sarx_rda_plan_create": (_i, [_vp, _i, _i, _P(RadarParams), _P(_vp)]),
     "sarx_rda_plan_destroy": (_i, [_vp]),
@@ -104,6 +105,8 @@ SIGNATURES = {
     "sarx_allgather_dev": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_comm_sync": (_i, [_vp]),
     "sarx_comm_fence_compute": (_i, [_vp]),
+    "sarx_comm_mark": (_i, [_vp, _i]),
+    "sarx_comm_wait_mark": (_i, [_vp, _i]),
     "sarx_comm_destroy": (_i, [_vp]),
 }
 

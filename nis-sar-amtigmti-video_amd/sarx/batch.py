@@ -177,7 +177,8 @@ class TwoChannelBatch:
     Per frame, all on the device and without a host round trip: CSA focus of both channels, ATI/DPCA products with
     the fp64 phase-balance sum, the 5 % magnitude mask (threshold from the device-side max), and the frame's stack
     slot:  stack="multilook": looks x looks mean of |slc1|^2 (1 MiB per 8192^2 frame - the display stack the
-    reference's batch script keeps, 512^2 per frame, sar_batch_sim.py:322);  stack="magnitude": |slc1| at full
+    reference's batch script keeps, 512^2 per frame, sar_batch_sim.py:322), emitted by channel 1's last azimuth launch
+    as row-wise partial sums and finished by a small launch (the image is not read again);  stack="magnitude": |slc1| at full
     resolution (256 MiB per 8192^2 frame: the configuration that loads xGMI).
 
     The stack lives in one device buffer [rounds][world][slot]; a frame's slot is produced directly at its place
@@ -232,10 +233,16 @@ class TwoChannelBatch:
             self.ctx.sync()
         self._prepared = True
 
-    def focus_frame(self, bufs):
-        """raw1, raw2 -> s1, s2, ATI/DPCA planes, masked phase.  Only enqueues (no host synchronisation)."""
+    def focus_frame(self, bufs, slot_ptr=None):
+        """raw1, raw2 -> s1, s2, ATI/DPCA planes, masked phase (and, for the multilook stack, channel 1's slot at slot_ptr,
+        emitted by the focus itself: sarx_csa_plan_set_look_slot).  Only enqueues (no host synchronisation)."""
         ctx = self.ctx
+        fused = slot_ptr is not None and self.stack_kind == "multilook"
+        if fused:
+            self.plan.set_look_slot(self.looks, slot_ptr)
         self.plan.focus_dev(bufs[0], self.s1)
+        if fused:
+            self.plan.set_look_slot(self.looks, None)
         self.plan.focus_dev(bufs[1], self.s2)
         ctx.ati_dpca(self.s1, self.s2, self.px, 0.0, self.outs, want_stats=False)
         ctx.mask_phase_frac(self.outs["ati_phase"], self.outs["slc1_mag"], self.px, self.mask_frac, self.masked)
@@ -244,11 +251,9 @@ class TwoChannelBatch:
         return self.d_stack.ptr + (i * self.world + r) * self.slot_bytes
 
     def write_slot(self, dst_ptr):
+        """The full-resolution magnitude slot (the multilook slot comes out of the focus itself)."""
         ctx = self.ctx
-        if self.stack_kind == "multilook":
-            from ._ffi import check
-            check(ctx.lib.sarx_multilook_dev(ctx.h, self.s1.ptr, dst_ptr, self.n, self.n, self.looks), ctx.h)
-        else:
+        if self.stack_kind == "magnitude":
             from ._ffi import check
             check(ctx.lib.sarx_magnitude_dev(ctx.h, self.s1.ptr, dst_ptr, self.px), ctx.h)
 
@@ -265,7 +270,7 @@ class TwoChannelBatch:
                 bufs = self.raw[i] if self.resident else self.raw[0]
                 if not self.resident:
                     self.synth_frame(self.mine[i], bufs)
-                self.focus_frame(bufs)
+                self.focus_frame(bufs, mine_ptr)
                 self.write_slot(mine_ptr)
             else:                                                   # pad round: zeros, never a stale slot
                 check(ctx.lib.sarx_memset(ctx.h, mine_ptr, 0, self.slot_bytes), ctx.h)

@@ -290,6 +290,11 @@ class CsaPlan:
         """focus_dev records ctx events around its range pass(es) (roofline kernel timing)."""
         check(self.ctx.lib.sarx_csa_plan_mark_range(self.h, int(slot_start), int(slot_stop)), self.ctx.h)
 
+    def set_look_slot(self, looks, slot_ptr):
+        """Every later focus_dev also writes the looks x looks multilook of |image|^2 to the device address slot_ptr
+        (None / 0 switches it off): the VideoSAR stack slot without reading the image again."""
+        check(self.ctx.lib.sarx_csa_plan_set_look_slot(self.h, int(looks), slot_ptr if slot_ptr else None), self.ctx.h)
+
     def focus_dev(self, d_phist, d_image):
         check(self.ctx.lib.sarx_csa_focus_dev(self.h, d_phist.ptr, d_image.ptr), self.ctx.h)
 

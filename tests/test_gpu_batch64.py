@@ -22,12 +22,18 @@ def _independent_slot(sarx, ctx, n, f, stack, looks=16, seed_base=1000):
     plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE)
     raw, s1 = ctx.alloc(px * 8), ctx.alloc(px * 8)
     ctx.fill_noise(raw, px, seed_base + 2 * f)
-    plan.focus_dev(raw, s1)
-    if stack == "multilook":
+    if stack == "multilook":                                  # the slot the focus itself emits (sarx_csa_plan_set_look_slot) ...
         d = ctx.alloc((n // looks) ** 2 * 4)
-        ctx.multilook(s1, d, n, n, looks)
+        plan.set_look_slot(looks, d.ptr)
+        plan.focus_dev(raw, s1)
         out = d.download(np.float32, (n // looks, n // looks))
+        d2 = ctx.alloc((n // looks) ** 2 * 4)                 # ... is the multilook of the finished image (other summation order)
+        ctx.multilook(s1, d2, n, n, looks)
+        ref = d2.download(np.float32, out.shape)
+        assert np.abs(out - ref).max() <= 2e-6 * ref.max()
+        d2.release()
     else:
+        plan.focus_dev(raw, s1)
         d = ctx.alloc(px * 4)
         ctx.magnitude(s1, d, px)
         out = d.download(np.float32, (n, n))

@@ -214,6 +214,39 @@ def test_corner_turn_multilook_noise(sx, ctx):
     assert abs(a.real.std() - 1) < 0.01 and abs(a.imag.std() - 1) < 0.01 and abs(a.mean()) < 0.01
 
 
+@pytest.mark.parametrize("n_az,n_rg,looks", [(512, 1024, 16), (128, 256, 4), (2048, 512, 32), (64, 64, 1)])
+def test_fused_look_slot(sx, ctx, n_az, n_rg, looks):
+    """sarx_csa_plan_set_look_slot: the multilooked intensity emitted by the focus itself equals the mean of |image|^2 over
+    looks x looks blocks of the image it wrote, is reproduced bit for bit, leaves the image untouched, and switches off again."""
+    from sarx import _ffi
+    raw, k = orc.point_scene(n_az, n_rg, seed=looks + n_az, clutter_db=-10.0)
+    args = orc.focus_args(k)
+    plan = _plan(sx, ctx, n_az, n_rg, args, flags=_ffi.FUSE_RANGE)
+    d_in, d_img, d_ref = ctx.to_device(raw), ctx.alloc(raw.nbytes), ctx.alloc(raw.nbytes)
+    nslot = (n_az // looks) * (n_rg // looks)
+    d_slot = ctx.alloc(nslot * 4 + 64)
+    plan.focus_dev(d_in, d_ref)
+    ctx.lib.sarx_memset(ctx.h, d_slot.ptr, 0xFF, nslot * 4 + 64)
+    plan.set_look_slot(looks, d_slot.ptr)
+    plan.focus_dev(d_in, d_img)
+    img = d_img.download(np.complex64, raw.shape)
+    np.testing.assert_array_equal(img, d_ref.download(np.complex64, raw.shape))
+    slot = d_slot.download(np.float32, (n_az // looks, n_rg // looks))
+    ref = (np.abs(img.astype(np.complex128)) ** 2).reshape(n_az // looks, looks, n_rg // looks, looks).mean(axis=(1, 3))
+    assert orc.rel_l2(slot, ref) < 1e-6
+    guard = d_slot.download(np.uint8, (nslot * 4 + 64,))[nslot * 4:]
+    assert (guard == 0xFF).all()                                  # nothing written past the slot
+    plan.focus_dev(d_in, d_img)
+    np.testing.assert_array_equal(d_slot.download(np.float32, slot.shape), slot)
+    plan.set_look_slot(looks, None)
+    ctx.lib.sarx_memset(ctx.h, d_slot.ptr, 0, nslot * 4)
+    plan.focus_dev(d_in, d_img)
+    assert not d_slot.download(np.float32, slot.shape).any()      # switched off
+    with pytest.raises(sx.SarxError):
+        plan.set_look_slot(3, d_slot.ptr)
+    plan.close()
+
+
 def test_errors_are_loud(sx, ctx):
     k = orc.scaled_radar(64, 64)
     with pytest.raises(sx.SarxError):
