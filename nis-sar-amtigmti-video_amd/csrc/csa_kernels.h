@@ -53,6 +53,7 @@ struct AzArgs {
     int io_shift_in;      // TWIDDLE_PADIN: sequence element r is source row (r + io_shift_in) mod io_rows (fftshift bookkeeping)
     int io_shift_out;     // CROPOUT*: sequence element r goes to destination row (r + io_shift_out) mod io_rows
     float* out_mag;       // CROPOUT_MAG: [io_rows x io_cols] fp32 magnitudes (leading dimension io_ld)
+    bool nt;              // nontemporal image loads / stores (images too large to be re-read from cache before they are evicted)
     float* look_part;     // SCALE_LOOK: [n_az x n_rg/look] row-wise partial sums of |x|^2 over `look` columns (a power of two <= tile width)
     int look;
     int valid_len;        // TWCOL / PROCOL (split lines): only the first valid_len samples of a line are read (rest = 0) / written; 0 = all

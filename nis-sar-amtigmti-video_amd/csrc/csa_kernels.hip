@@ -186,6 +186,19 @@ template <int R, int W> struct AzCfg {
     static constexpr size_t LDS_BYTES = (PL::nstages > 1) ? (size_t)LdsSize<R, W>::value * sizeof(cf) : 0;
 };
 
+// Image loads / stores of the azimuth tiles, nontemporal on request: an image of a gigabyte or more is not re-read before
+// 2+ GiB of other traffic has passed, so keeping its lines in L2 / the Infinity Cache only evicts what could be reused;
+// on the 16384^2 tile copies of tools/membench.hip nontemporal accesses are 4.5-7.6 % faster (0.758 / 0.778 vs 0.820 / 0.815 ms).
+typedef float nt_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf ld_stream(const cf* p, bool nt) {
+    if (nt) { const nt_v2f v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2f*>(p)); return make_float2(v.x, v.y); }
+    return *p;
+}
+__device__ __forceinline__ void st_stream(cf* p, cf x, bool nt) {
+    if (nt) __builtin_nontemporal_store(nt_v2f{x.x, x.y}, reinterpret_cast<nt_v2f*>(p));
+    else *p = x;
+}
+
 template <int R, int W, bool INV, int EPI>
 __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs a) {
     using PL = Plan<R>;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             } else if constexpr (EPI == AZ_EPI_TWCOL) {   // zero-padded line: the padding is not stored, let alone read
                 x = (a.valid_len && mi * a.n_rg + col >= a.valid_len) ? make_float2(0.f, 0.f) : a.in[rowi * a.n_rg + col];
             } else {
-                x = a.in[rowi * a.n_rg + col];
+                x = ld_stream(a.in + rowi * a.n_rg + col, a.nt);
             }
             if constexpr (EPI == AZ_EPI_PROCOL) {      // inverse of the 32768-point line split: W_M^(+-col*m_in) first
                 const float rev = (float)(col * mi) * a.tw_scale;
@@ -286,7 +299,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                 const float rev = (float)(col * m) * a.tw_scale;
                 x = cmul(x, cis_frac(INV ? rev : -rev));
             }
-            a.out[rowo * a.n_rg + col] = x;
+            st_stream(a.out + rowo * a.n_rg + col, x, a.nt);
         }
 }
 

@@ -65,6 +65,26 @@ __global__ __launch_bounds__(8 * W / VEC) void tile_copy(const float2* __restric
     }
 }
 
+// the same tile copy with nontemporal loads (NT & 1) and / or stores (NT & 2), 8 B per lane
+template <int W, int NT>
+__global__ __launch_bounds__(8 * W) void tile_copy_nt(const float2* __restrict__ in, float2* __restrict__ out, int n_rg,
+                                                      int in_q, int in_m, int out_q, int out_m) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int c = threadIdx.x % W, t = threadIdx.x / W;
+    const int col = blockIdx.x * W + c, q = blockIdx.y;
+    v2f v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const v2f* p = reinterpret_cast<const v2f*>(&in[((size_t)q * in_q + (size_t)(t + 8 * i) * in_m) * n_rg + col]);
+        v[i] = (NT & 1) ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v2f* p = reinterpret_cast<v2f*>(&out[((size_t)q * out_q + (size_t)(t + 8 * i) * out_m) * n_rg + col]);
+        if (NT & 2) __builtin_nontemporal_store(v[i], p); else *p = v[i];
+    }
+}
+
 // line copy shaped like the range pass: one 16384-sample line per workgroup of T threads,
 // each thread PTS samples at stride T (VEC float2 per access), LDS bytes reserved to set residency
 template <int T, int PTS, int VEC>
@@ -140,6 +160,11 @@ int main() {
     rep("az step B  W=64 16B/lane", time_ms([&] { hipLaunchKernelGGL((tile_copy<64, 2>), dim3(n / 64, RA), dim3(256), 0, 0, in, out, n, S, 1, 1, RA); }));
     rep("az step B  W=128 16B/lane", time_ms([&] { hipLaunchKernelGGL((tile_copy<128, 2>), dim3(n / 128, RA), dim3(512), 0, 0, in, out, n, S, 1, 1, RA); }));
 
+    rep("az step A  W=32  8B nt stores", time_ms([&] { hipLaunchKernelGGL((tile_copy_nt<32, 2>), dim3(n / 32, S), dim3(256), 0, 0, in, out, n, 1, S, 1, S); }));
+    rep("az step A  W=32  8B nt both", time_ms([&] { hipLaunchKernelGGL((tile_copy_nt<32, 3>), dim3(n / 32, S), dim3(256), 0, 0, in, out, n, 1, S, 1, S); }));
+    rep("az step B  W=32  8B nt stores", time_ms([&] { hipLaunchKernelGGL((tile_copy_nt<32, 2>), dim3(n / 32, RA), dim3(256), 0, 0, in, out, n, S, 1, 1, RA); }));
+    rep("az step B  W=32  8B nt both", time_ms([&] { hipLaunchKernelGGL((tile_copy_nt<32, 3>), dim3(n / 32, RA), dim3(256), 0, 0, in, out, n, S, 1, 1, RA); }));
+    rep("az step B  W=32  8B plain (again)", time_ms([&] { hipLaunchKernelGGL((tile_copy_nt<32, 0>), dim3(n / 32, RA), dim3(256), 0, 0, in, out, n, S, 1, 1, RA); }));
     // range-line copies at different residency
     auto set_lds = [&](const void* k, int bytes) { CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); };
     set_lds((const void*)line_copy<1024, 16, 1>, 139264);
