@@ -108,6 +108,7 @@ struct PfaArgs {
     const double2* c1; double dt, t_start;             // Phi_1 epilogue
     float scale;                                       // inverse: 1/7199
     int c1k, c2k;                                      // output map k = (c1k k1 + c2k k2) mod 7199
+    bool nt;                                           // nontemporal image loads / stores
 };
 struct AzPfa;
 bool az_pfa_supported(int n_az);
@@ -134,6 +135,7 @@ struct AtiArgs {
     float* ph1;
     float* ph2;
     float* dpca_phase;
+    bool nt;              // nontemporal loads of the two images (their last use)
     float* part_max;      // [blocks]
     double2* part_sum;    // [blocks]
 };

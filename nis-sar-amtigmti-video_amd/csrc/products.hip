@@ -44,6 +44,11 @@ template <bool OPT> __device__ __forceinline__ void ati_pixel(cf a, cf b, float 
     }
 }
 
+typedef float nt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float4* p, bool nt) {
+    if (nt) { const nt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const nt_v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *p;
+}
 // Four pixels per lane: two 16-byte loads per channel, one 16-byte store per fp32 plane (28 B/pixel in all).
 template <bool OPT> __global__ __launch_bounds__(ATI_THREADS) void ati_dpca_kernel(AtiArgs a) {
     const size_t nquad = a.n / 4;
@@ -53,7 +58,7 @@ template <bool OPT> __global__ __launch_bounds__(ATI_THREADS) void ati_dpca_kern
     const float4* s1 = reinterpret_cast<const float4*>(a.s1);
     const float4* s2 = reinterpret_cast<const float4*>(a.s2);
     for (size_t i = (size_t)blockIdx.x * ATI_THREADS + threadIdx.x; i < nquad; i += stride) {
-        const float4 x0 = s1[2 * i], x1 = s1[2 * i + 1], y0 = s2[2 * i], y1 = s2[2 * i + 1];
+        const float4 x0 = ld4(s1 + 2 * i, a.nt), x1 = ld4(s1 + 2 * i + 1, a.nt), y0 = ld4(s2 + 2 * i, a.nt), y1 = ld4(s2 + 2 * i + 1, a.nt);
         Pix p[4];
         ati_pixel<OPT>(make_float2(x0.x, x0.y), make_float2(y0.x, y0.y), a.cal_c, a.cal_s, p[0]);
         ati_pixel<OPT>(make_float2(x0.z, x0.w), make_float2(y0.z, y0.w), a.cal_c, a.cal_s, p[1]);

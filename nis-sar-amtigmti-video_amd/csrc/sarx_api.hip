@@ -736,6 +736,9 @@ int sarx_ati_dpca_dev(sarx_ctx* c, const void* s1, const void* s2, size_t n, dou
     a.interf = (float2*)o->ati_interf; a.diff = (float2*)o->dpca_diff;
     a.mag2 = o->slc2_mag; a.ph1 = o->slc1_phase; a.ph2 = o->slc2_phase; a.dpca_phase = o->dpca_phase;
     a.part_max = c->ati_part_max; a.part_sum = c->ati_part_sum;
+    // the two images are read for the last time here: nontemporal loads once they are too large to still be cached
+    // (0.341 -> 0.329 ms at 8192^2); SARX_ATI_NT=0/1 overrides
+    { static const int nt = [] { const char* e = getenv("SARX_ATI_NT"); return e ? atoi(e) : -1; }(); a.nt = nt < 0 ? n >= ((size_t)1 << 25) : nt != 0; }
     HIPCHK(c, launch_ati_dpca(a, c->stream));
     HIPCHK(c, launch_ati_finish(c->ati_part_max, c->ati_part_sum, ati_blocks(n), c->ati_out3, c->stream));
     if (max_mag || sum2) {
