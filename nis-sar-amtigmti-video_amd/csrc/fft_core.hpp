@@ -39,6 +39,27 @@ template <bool INV> __device__ __forceinline__ cf mul_w8_3(cf a) {
     return INV ? make_float2(-h * (a.x + a.y), h * (a.x - a.y)) : make_float2(h * (a.y - a.x), -h * (a.x + a.y));
 }
 
+// ---- streaming image accesses ---------------------------------------------------------------------------------------
+// Compile-time nontemporal variants (NT) for kernels whose register budget has no room for a run-time choice.
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 ld16(const cf* p) {
+    if constexpr (NT) { const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    else return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT> __device__ __forceinline__ void st16(cf* p, float4 x) {
+    if constexpr (NT) __builtin_nontemporal_store(nt_f4{x.x, x.y, x.z, x.w}, reinterpret_cast<nt_f4*>(p));
+    else *reinterpret_cast<float4*>(p) = x;
+}
+template <bool NT> __device__ __forceinline__ cf ld8(const cf* p) {
+    if constexpr (NT) { const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(p)); return make_float2(v.x, v.y); }
+    else return *p;
+}
+template <bool NT> __device__ __forceinline__ void st8(cf* p, cf x) {
+    if constexpr (NT) __builtin_nontemporal_store(nt_f2{x.x, x.y}, reinterpret_cast<nt_f2*>(p));
+    else *p = x;
+}
+
 // ---- in-register DFTs, natural order in and out; stride S between elements ----
 template <bool INV> __device__ __forceinline__ void dft2(cf& a, cf& b) {
     cf t = a;

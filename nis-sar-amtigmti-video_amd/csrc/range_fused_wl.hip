@@ -113,7 +113,7 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
         cf v[32];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float4 q4 = *reinterpret_cast<const float4*>(src + 2 * t + r * M);
+            const float4 q4 = ld16<false>(src + 2 * t + r * M);
             v[r] = make_float2(q4.x, q4.y);
             v[16 + r] = make_float2(q4.z, q4.w);
         }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
                 cf p0 = q0.next(), p1 = q1.next();
                 p0.x *= sc; p0.y *= sc; p1.x *= sc; p1.y *= sc;
                 const cf y0 = cmul(v[n1], p0), y1 = cmul(v[16 + n1], p1);
-                *reinterpret_cast<float4*>(dst + 2 * t + n1 * M) = make_float4(y0.x, y0.y, y1.x, y1.y);
+                st16<false>(dst + 2 * t + n1 * M, make_float4(y0.x, y0.y, y1.x, y1.y));
             }
         }
     }

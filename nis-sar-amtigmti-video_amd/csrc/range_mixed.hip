@@ -93,7 +93,7 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
             // stage 1: radix R1, NS = 1, straight from HBM (8 bytes per lane, consecutive lanes consecutive samples)
             if (t < G1) {
 #pragma unroll
-                for (int r = 0; r < R1; ++r) v[r] = src[t + r * G1];
+                for (int r = 0; r < R1; ++r) v[r] = ld8<false>(src + t + r * G1);
                 mix::dft_any<R1, false>(v);
                 cross1_write<R1, C::PITCH_F1>(v, t, lds);
             }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
                     for (int r = 0; r < R1; ++r) {
                         cf ph = q.next();
                         ph.x *= s; ph.y *= s;
-                        dst[t + r * G1] = cmul(v[r], ph);
+                        st8<false>(dst + t + r * G1, cmul(v[r], ph));
                     }
                 }
             }

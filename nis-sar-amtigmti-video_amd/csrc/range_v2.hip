@@ -15,6 +15,10 @@
 #include "fft_core.hpp"
 #include "phase.hpp"
 
+#ifndef SARX_NT_V2
+#define SARX_NT_V2 3      // bit 0: nontemporal line loads, bit 1: nontemporal line stores (16384-sample lines only)
+#endif
+
 namespace sarx {
 
 template <int N> struct V2 {
@@ -118,7 +122,7 @@ template <int N, int R> __device__ __forceinline__ void v2_load(cf* v, int t, co
     for (int b = 0; b < B; b += 2)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float4 q = *reinterpret_cast<const float4*>(src + V2<N>::j(t, b) + r * (N / R));
+            const float4 q = ld16<((SARX_NT_V2 & 1) && N == 16384)>(src + V2<N>::j(t, b) + r * (N / R));
             v[b * R + r] = make_float2(q.x, q.y);
             v[(b + 1) * R + r] = make_float2(q.z, q.w);
         }
@@ -129,8 +133,8 @@ template <int N, int R> __device__ __forceinline__ void v2_store(const cf* v, in
     for (int b = 0; b < B; b += 2)
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            *reinterpret_cast<float4*>(dst + V2<N>::j(t, b) + r * (N / R)) =
-                make_float4(v[b * R + r].x, v[b * R + r].y, v[(b + 1) * R + r].x, v[(b + 1) * R + r].y);
+            st16<((SARX_NT_V2 & 2) && N == 16384)>(dst + V2<N>::j(t, b) + r * (N / R),
+                make_float4(v[b * R + r].x, v[b * R + r].y, v[(b + 1) * R + r].x, v[(b + 1) * R + r].y));
 }
 
 // After the last stage (radix RL) register (b, r) holds output index
@@ -172,7 +176,7 @@ __device__ __forceinline__ void v2_row(const RangeArgs& a, int row, bool live, i
                     v[r0] = cmul(v[r0], q0.next());
                     v[r1] = cmul(v[r1], q1.next());
                     if constexpr (MODE == RG_FFT_PHI2) {
-                        if (live) *reinterpret_cast<float4*>(dst + 2 * t + 2 * T * m) = make_float4(v[r0].x, v[r0].y, v[r1].x, v[r1].y);
+                        if (live) st16<((SARX_NT_V2 & 2) && N == 16384)>(dst + 2 * t + 2 * T * m, make_float4(v[r0].x, v[r0].y, v[r1].x, v[r1].y));
                     }
                 }
             }
@@ -199,7 +203,7 @@ __device__ __forceinline__ void v2_row(const RangeArgs& a, int row, bool live, i
             cf p0 = q0.next(), p1 = q1.next();
             p0.x *= s; p0.y *= s; p1.x *= s; p1.y *= s;
             const cf y0 = cmul(v[r0], p0), y1 = cmul(v[r1], p1);
-            if (live) *reinterpret_cast<float4*>(dst + 2 * t + 2 * T * m) = make_float4(y0.x, y0.y, y1.x, y1.y);
+            if (live) st16<((SARX_NT_V2 & 2) && N == 16384)>(dst + 2 * t + 2 * T * m, make_float4(y0.x, y0.y, y1.x, y1.y));
         }
     }
 }
