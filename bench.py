@@ -39,8 +39,8 @@ LOOKS = 16
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE or 1)")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--unfused", action="store_true", help="run range passes 2 and 3 as two launches")
     ap.add_argument("--passes", action="store_true", help="also print every pass alone to stderr")
