@@ -116,6 +116,9 @@ int sarx_csa_axes(const sarx_plan* plan, double* range_axis, double* cross_range
 /* host in / host out, blocking: upload, four passes, download.
  * phist: [n_az x n_rg] complex64 row-major.  image: n_az*n_rg complex64 in the plan's layout. */
 int sarx_csa_focus_host(sarx_plan* plan, const void* phist_host, void* image_host);
+/* the same with phist as complex128 (the dtype the reference's arrays have, sar_ati_dcpa_sim_csa.py:135): rounded to complex64
+ * while it is staged for the transfer, by the copy threads; the image comes back as complex64 */
+int sarx_csa_focus_host_c128(sarx_plan* plan, const void* phist_c128_host, void* image_host);
 /* device in / device out, asynchronous on the ctx stream.  d_phist is not modified.
  * d_image must not alias d_phist. */
 int sarx_csa_focus_dev(sarx_plan* plan, const void* d_phist, void* d_image);

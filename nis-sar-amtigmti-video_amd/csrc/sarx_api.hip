@@ -150,10 +150,12 @@ static int fail(sarx_ctx* c, int code, const char* fmt, ...) {
 // Host <-> device copy of a large pageable buffer.  hipMemcpy from pageable memory runs at 8 GB/s here and into untouched
 // memory (a fresh NumPy array) at 13 GB/s (tools/pcibench.hip); eight threads staging 32 MiB chunks through pinned buffers reach
 // 51-54 GB/s both ways.  Blocking; ordered after everything on the ctx stream.  Small copies take the plain path.
-static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device) {
+// narrow: (host -> device only) the host buffer holds complex128 and is rounded to complex64 on the way into the pinned chunk
+// (the reference's arrays are complex128; a NumPy astype of 2^28 elements costs more than the whole transfer)
+static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, bool narrow = false) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return e;
-    if (bytes < 4 * sarx_ctx::COPY_CHUNK) {
+    if (bytes < 4 * sarx_ctx::COPY_CHUNK && !narrow) {
         e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, c->stream);
         return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
     }
@@ -175,7 +177,13 @@ static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t by
                 if (to_device) {
                     r = hipStreamSynchronize(c->copy_stream[i]);           // the chunk's previous DMA has left the pinned buffer
                     if (r != hipSuccess) break;
-                    memcpy(c->pin[i], s0 + off, len);
+                    if (narrow) {
+                        const double* in = (const double*)s0 + off / sizeof(float);      // off counts complex64 bytes: 2 floats <-> 2 doubles
+                        float* out = (float*)c->pin[i];
+                        for (size_t k = 0; k < len / sizeof(float); ++k) out[k] = (float)in[k];
+                    } else {
+                        memcpy(c->pin[i], s0 + off, len);
+                    }
                     r = hipMemcpyAsync(d + off, c->pin[i], len, hipMemcpyHostToDevice, c->copy_stream[i]);
                 } else {
                     r = hipMemcpyAsync(c->pin[i], s0 + off, len, hipMemcpyDeviceToHost, c->copy_stream[i]);
@@ -683,6 +691,21 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     }
     if ((rc = look_finish(p)) != SARX_OK) return rc;
     if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
+    return SARX_OK;
+}
+
+int sarx_csa_focus_host_c128(sarx_plan* p, const void* phist_host, void* image_host) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!phist_host || !image_host) return fail(c, SARX_ERR_INVALID, "NULL host pointer");
+    const size_t img = (size_t)p->n_az * p->n_rg * sizeof(float2);
+    if (!p->h_in) { hipError_t e = hipMalloc(&p->h_in, img); if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc staging: %s", hipGetErrorString(e)); }
+    if (!p->h_out) { hipError_t e = hipMalloc(&p->h_out, img); if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc staging: %s", hipGetErrorString(e)); }
+    HIPCHK(c, staged_copy(c, p->h_in, phist_host, img, true, true));
+    int rc = sarx_csa_focus_dev(p, p->h_in, p->h_out);
+    if (rc != SARX_OK) return rc;
+    HIPCHK(c, staged_copy(c, image_host, p->h_out, img, false));
     return SARX_OK;
 }
 

@@ -71,6 +71,7 @@ SIGNATURES = {
     "sarx_csa_plan_destroy": (_i, [_vp]),
     "sarx_csa_axes": (_i, [_vp, _vp, _vp]),
     "sarx_csa_focus_host": (_i, [_vp, _vp, _vp]),
+    "sarx_csa_focus_host_c128": (_i, [_vp, _vp, _vp]),
     "sarx_csa_focus_dev": (_i, [_vp, _vp, _vp]),
     "sarx_csa_pass": (_i, [_vp, _i, _vp, _vp]),
     "sarx_csa_plan_mark_range": (_i, [_vp, _i, _i]),

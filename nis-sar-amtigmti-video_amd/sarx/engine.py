@@ -278,12 +278,16 @@ class CsaPlan:
 
     def focus_host(self, phist_c64):
         """[n_az x n_rg] complex64 host array -> focused image in the plan's layout (host)."""
-        a = np.ascontiguousarray(phist_c64, dtype=np.complex64)
+        a = np.asarray(phist_c64)
+        wide = a.dtype == np.complex128 and a.flags.c_contiguous        # the reference's dtype: narrowed by the library's copy threads
+        if not wide:
+            a = np.ascontiguousarray(a, dtype=np.complex64)
         if a.shape != (self.n_az, self.n_rg):
             raise ValueError(f"phist shape {a.shape} != plan ({self.n_az}, {self.n_rg})")
         shape = (self.n_rg, self.n_az) if self.rg_major else (self.n_az, self.n_rg)
         out = np.empty(shape, dtype=np.complex64)
-        check(self.ctx.lib.sarx_csa_focus_host(self.h, a.ctypes.data, out.ctypes.data), self.ctx.h)
+        fn = self.ctx.lib.sarx_csa_focus_host_c128 if wide else self.ctx.lib.sarx_csa_focus_host
+        check(fn(self.h, a.ctypes.data, out.ctypes.data), self.ctx.h)
         return out
 
     def mark_range(self, slot_start=-1, slot_stop=-1):

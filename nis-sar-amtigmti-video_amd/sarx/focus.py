@@ -69,7 +69,7 @@ def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
         img = d_img.download(np.complex64, (n_rg, n_az) if materialize_transpose else (n_az, n_rg))
         d_img.release()
     else:
-        img = plan.focus_host(a.astype(np.complex64, copy=False))
+        img = plan.focus_host(a)              # complex128 input is narrowed inside the library while it is staged
     range_axis, cross_range_axis = plan.axes()
     return (img if materialize_transpose else img.T), range_axis, cross_range_axis
 

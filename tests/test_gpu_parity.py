@@ -126,6 +126,12 @@ def test_layouts_and_fusion_agree(sx):
     # complex128 input is accepted (reference dtype) and rounded once to complex64
     d = sx.sar_focus_csa(raw.astype(np.complex128), *args)[0]
     np.testing.assert_array_equal(a, d)
+    # ... by the library's copy threads when contiguous (sarx_csa_focus_host_c128), by NumPy otherwise: the same rounding
+    wide = raw.astype(np.complex128) * (1 + 1e-9) + 1e-12j
+    e = sx.sar_focus_csa(wide, *args)[0]
+    np.testing.assert_array_equal(e, sx.sar_focus_csa(wide.astype(np.complex64), *args)[0])
+    strided = np.asfortranarray(wide)
+    np.testing.assert_array_equal(e, sx.sar_focus_csa(strided, *args)[0])
 
 
 def test_linearity_and_determinism(sx):

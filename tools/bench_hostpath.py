@@ -21,3 +21,13 @@ for rep in range(3):
     img, rax, cax = sarx.sar_focus_csa(raw, *args)
     dt = time.perf_counter() - t0
     print(f"sar_focus_csa {n}x{n} host in / host out: {dt * 1e3:.1f} ms wall ({2 * raw.nbytes / dt / 1e9:.1f} GB/s over both directions)")
+raw128 = raw.astype(np.complex128)
+for rep in range(2):
+    t0 = time.perf_counter()
+    img2, _, _ = sarx.sar_focus_csa(raw128, *args)
+    dt = time.perf_counter() - t0
+    print(f"sar_focus_csa {n}x{n} complex128 in (the reference's dtype) / complex64 out: {dt * 1e3:.1f} ms wall")
+assert np.array_equal(img, img2)
+t0 = time.perf_counter()
+raw128.astype(np.complex64)
+print(f"  (numpy astype(complex64) of that input alone: {(time.perf_counter() - t0) * 1e3:.1f} ms)")
