@@ -48,7 +48,10 @@ static_assert(N1 * P == N && RA * RB == L, "factorisation");
 // (5.0 TB/s), arithmetic alone 0.20 ms, together 0.46 ms - with one 768-thread workgroup per CU (78 KiB image, 101 VGPRs)
 // the two do not overlap.  Tried and dropped: 13 threads per column with two butterflies each so that two 416-thread
 // workgroups fit a CU (0.72 ms: the serial work per thread doubles), 16-column tiles (two workgroups per CU, 0.46 ms),
-// prefetching the next n1's rows into a second register set (168 VGPRs + 292 B of scratch per lane).
+// prefetching the next n1's rows into a second register set (168 VGPRs + 292 B of scratch per lane), and a persistent form
+// that stages the next tile in 26 VGPRs and passes it through LDS (tools/rader_prefetch.patch: 0.432-0.437 vs 0.445 ms; with the
+// arithmetic alone at 0.268 ms, loads add 0.05, stores 0.06, both 0.17 - tools/overlapbench.hip shows the same for any
+// workgroup that runs its waves in lockstep on 128 KiB tiles).
 template <int W>
 __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
     using namespace pfa;
@@ -56,11 +59,13 @@ __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
     cf* lds = reinterpret_cast<cf*>(smem_raw);                   // [312][W]
     unsigned* tin = reinterpret_cast<unsigned*>(lds + (size_t)L * W);   // 23 g^q rows of the source, in bytes
     unsigned* tout = tin + L;                                            // g^-m rows of the intermediate, in bytes
+    cf* bsp = reinterpret_cast<cf*>(tout + L);                           // spectrum of w': read mid-tile, and a global load there would
+                                                                         // make the in-order vmcnt wait for everything issued before it
     const unsigned c = threadIdx.x % W, j = threadIdx.x / W;     // j in [0, 24)
     const unsigned col = blockIdx.x * W + c, n1 = blockIdx.y;
     const bool live = (int)col < a.in_cols;
     const unsigned colb = col * (unsigned)sizeof(cf);
-    for (int i = threadIdx.x; i < L; i += RA * W) { tin[i] = a.offin[i]; tout[i] = a.offu[i]; }
+    for (int i = threadIdx.x; i < L; i += RA * W) { tin[i] = a.offin[i]; tout[i] = a.offu[i]; bsp[i] = a.bspec[i]; }
     __syncthreads();
     const char* __restrict__ src = reinterpret_cast<const char*>(a.in);
     char* __restrict__ dst = reinterpret_cast<char*>(a.u);
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
     // times the spectrum of w' (carries the 1/312 of the convolution); the DC bin also gives y[0] and takes a[0]
     if (j == 0) y0 = cadd(a0, v[0]);
 #pragma unroll
-    for (int r = 0; r < RB; ++r) v[r] = cmul(v[r], a.bspec[j + RA * r]);
+    for (int r = 0; r < RB; ++r) v[r] = cmul(v[r], bsp[j + RA * r]);
     if (j == 0) v[0] = cadd(v[0], a0);
     // inverse FFT_312, radices reversed: stage 1 radix 13 on the registers as they are
     mix::dft_any<RB, true>(v);
@@ -238,7 +243,7 @@ hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, in
     // every image here is 0.76 GB and is next read a whole launch later: nontemporal accesses (2.19 -> 2.13 ms per native frame);
     // SARX_PFA_NT=0 for A/B
     { static const int nt = [] { const char* e = getenv("SARX_PFA_NT"); return e ? atoi(e) : 1; }(); a.nt = nt != 0; }
-    const size_t lds = (size_t)L * W * sizeof(cf) + 2 * L * sizeof(unsigned);     // image + this n1's two offset tables
+    const size_t lds = (size_t)L * W * sizeof(cf) + 2 * L * sizeof(unsigned) + L * sizeof(cf);     // image + the two offset tables + the spectrum of w'
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfa_rader313_kernel<W>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
