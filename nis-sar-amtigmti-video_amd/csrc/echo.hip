@@ -12,8 +12,12 @@
 // staged through LDS, phase summed and reduced in fp64, sine/cosine and accumulation fp32.
 // run_physics_spotlight (sar_batch_sim.py:145-149) is the same loop with u = t_fast - tau (no Tp/2 offset)
 // and an amplitude per pulse and target (rcs times the antenna pattern): amp_pt, u_off = 0.
-// Compute-bound (28 issue slots per target-sample, no reuse of HBM data), so no roofline
-// in bytes: 5000 targets x 7200 x 13200 = 4.8e11 target-samples.
+// Compute-bound (no reuse of HBM data), so no roofline in bytes: 5000 targets x 7200 x 13200 = 4.8e11 target-samples in
+// 174 ms = 58 SIMD cycles per wave of 64 target-samples, i.e. 14 four-cycle issue slots of which the sine/cosine pair
+// takes four.  fp64 adds and FMAs issue at the fp32 rate on this part, so the fp64 gate and phase are not the cost:
+// a round-2 variant with 16 consecutive samples per thread, the pulse gate tested at the run's ends only and the phase
+// stepped as the 32-bit fixed-point accumulator of phase.hpp (no fp64 per sample) passed the same parity tests and took
+// 229 ms (113 VGPRs, half the occupancy, divergent edge runs).  Dropped.
 #include "csa_kernels.h"
 #include "fft_core.hpp"
 
