@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 200
+#define SARX_VERSION 201
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -134,6 +134,13 @@ int sarx_csa_plan_mark_range(sarx_plan* plan, int slot_start, int slot_stop);
  * finishes them, so the 2 GiB image is not read again.  looks: a power of two <= 32 dividing both extents; power-of-two plans
  * only; the slot is [n_az/looks x n_rg/looks] whatever the image layout.  d_slot = NULL switches it off.  Bitwise reproducible. */
 int sarx_csa_plan_set_look_slot(sarx_plan* plan, int looks, float* d_slot);
+#define SARX_MAX_SLOT_BYTES 32768  /* 256 partial maxima, one per 128-byte line: atomics on one address would serialise */
+/* max |image| fused into the focus: while d_max is set, every sarx_csa_focus_dev of this plan also leaves max |image| (fp32, the
+ * hypotf the ATI launch computes) in d_max[SARX_MAX_SLOT_BYTES] as 256 partial maxima (float k*32, the rest zero; the maximum is
+ * their maximum) - the last azimuth launch reduces them while it writes the image - so that
+ * sarx_ati_dpca_masked_dev can apply the 5 % mask (sar_ati_dcpa_sim_csa.py:447-449) in the ATI pass itself instead of a further
+ * pass over two planes.  Power-of-two plans and the native 7199 x 13200; d_max = NULL switches it off. */
+int sarx_csa_plan_set_max_slot(sarx_plan* plan, float* d_max);
 /* bytes of HBM scratch the plan holds (two ping-pong images + tables) */
 int sarx_csa_plan_bytes(const sarx_plan* plan, uint64_t* out_bytes);
 
@@ -183,6 +190,11 @@ int sarx_ati_dpca_dev(sarx_ctx* ctx, const void* d_slc1, const void* d_slc2, siz
 /* All ATI/DPCA buffers must be 16-byte aligned.  With max_mag and sum_interf_re_im both NULL the call only enqueues;
  * sarx_ati_stats fetches the two reductions of the most recent launch on this ctx later (blocking). */
 int sarx_ati_stats(sarx_ctx* ctx, double* max_mag, double* sum_interf_re_im /*[2]*/);
+/* The same launch with the magnitude mask applied on the way out: d_out->ati_phase receives ati_phase where
+ * |slc1| > mask_frac * max|slc1| and 0 elsewhere (:447-449); d_max = the SARX_MAX_SLOT_BYTES slot sarx_csa_plan_set_max_slot of
+ * the plan that focused slc1 filled (or 256 floats, 32 apart, the caller put there).  Only enqueues; sarx_ati_stats works as after sarx_ati_dpca_dev. */
+int sarx_ati_dpca_masked_dev(sarx_ctx* ctx, const void* d_slc1, const void* d_slc2, size_t n, double cal_phase, const float* d_max,
+                             float mask_frac, const sarx_ati_outputs* d_out);
 /* ati_phase[~(mag > mask_frac * max|slc1|)] = 0 with the maximum taken on the device from the most recent
  * sarx_ati_dpca_dev launch of this ctx (sar_ati_dcpa_sim_csa.py:447-449 without a host round trip) */
 int sarx_mask_phase_frac_dev(sarx_ctx* ctx, const float* d_phase, const float* d_mag, size_t n, float mask_frac,

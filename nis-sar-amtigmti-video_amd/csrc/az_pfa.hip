@@ -126,26 +126,39 @@ __global__ __launch_bounds__(256) void pfa_dft23_kernel(PfaArgs a) {
     using namespace pfa;
     const unsigned col = blockIdx.x * 64 + (threadIdx.x & 63);
     const unsigned k2 = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if ((int)col >= a.out_cols || k2 >= (unsigned)P) return;
-    const unsigned colb = col * (unsigned)sizeof(cf);
-    const char* __restrict__ src = reinterpret_cast<const char*>(a.u);
-    char* __restrict__ dst = reinterpret_cast<char*>(a.out);
-    cf v[N1];
-    unsigned o = k2 * a.pitch_u + colb;                          // row n1*313 + k2: byte offset advances by 313 rows
+    const bool live = (int)col < a.out_cols && k2 < (unsigned)P;
+    float vmax = 0.f;
+    if (live) {
+        const unsigned colb = col * (unsigned)sizeof(cf);
+        const char* __restrict__ src = reinterpret_cast<const char*>(a.u);
+        char* __restrict__ dst = reinterpret_cast<char*>(a.out);
+        cf v[N1];
+        unsigned o = k2 * a.pitch_u + colb;                          // row n1*313 + k2: byte offset advances by 313 rows
 #pragma unroll
-    for (int n1 = 0; n1 < N1; ++n1) { v[n1] = ldnt(src + o, a.nt); o += a.off0u; }
-    mix::dft_any<N1, INV>(v);
-    unsigned row = (unsigned)(((unsigned long long)a.c2k * k2) % N);
-    unsigned oo = row * a.pitch_out + colb;
-    const unsigned step = (unsigned)a.c1k * a.pitch_out, wrap = (unsigned)N * a.pitch_out;
+        for (int n1 = 0; n1 < N1; ++n1) { v[n1] = ldnt(src + o, a.nt); o += a.off0u; }
+        mix::dft_any<N1, INV>(v);
+        unsigned row = (unsigned)(((unsigned long long)a.c2k * k2) % N);
+        unsigned oo = row * a.pitch_out + colb;
+        const unsigned step = (unsigned)a.c1k * a.pitch_out, wrap = (unsigned)N * a.pitch_out;
 #pragma unroll
-    for (int k1 = 0; k1 < N1; ++k1) {
-        cf x = v[k1];
-        if constexpr (EPI == 1) x = cmul(x, phi1((int)col, a.c1[row], a.dt, a.t_start));
-        else if constexpr (EPI == 2) { x.x *= a.scale; x.y *= a.scale; }
-        stnt(dst + oo, x, a.nt);
-        row += a.c1k; oo += step;
-        if (row >= (unsigned)N) { row -= N; oo -= wrap; }
+        for (int k1 = 0; k1 < N1; ++k1) {
+            cf x = v[k1];
+            if constexpr (EPI == 1) x = cmul(x, phi1((int)col, a.c1[row], a.dt, a.t_start));
+            else if constexpr (EPI == 2) {
+                x.x *= a.scale; x.y *= a.scale;
+                if (a.max_out) vmax = fmaxf(vmax, hypotf(x.x, x.y));      // max |image| for the ATI mask, as in az_tile_kernel
+            }
+            stnt(dst + oo, x, a.nt);
+            row += a.c1k; oo += step;
+            if (row >= (unsigned)N) { row -= N; oo -= wrap; }
+        }
+    }
+    if constexpr (EPI == 2) {
+        if (a.max_out) {        // every lane arrives here (dead lanes carry 0): one sharded atomic per wave
+            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+            if ((threadIdx.x & 63) == 0)
+                atomicMax(a.max_out + 32u * ((blockIdx.x * 7u + blockIdx.y * 13u + (threadIdx.x >> 6)) & (MAX_SHARDS - 1u)), __float_as_uint(vmax));
+        }
     }
 }
 
@@ -228,7 +241,7 @@ AzPfa* az_pfa_create(size_t in_ld, size_t u_ld, size_t out_ld, hipError_t* err) 
 // dst: dense [7199 x dst_cols]; epi: 0 none, 1 Phi_1 (a.c1 / dt / t_start must be set), 2 scale
 hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, int src_cols, cf* u, size_t u_ld, cf* dst,
                       size_t dst_ld, int dst_cols, int epi, const double2* c1, double dt, double t_start, float scale,
-                      hipStream_t st) {
+                      hipStream_t st, unsigned* max_out) {
     using namespace pfa;
     constexpr int W = 32;
     PfaArgs a{};
@@ -237,6 +250,7 @@ hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, in
     a.out = dst; a.out_ld = dst_ld; a.out_cols = dst_cols;
     a.offin = z->offin; a.offu = z->offu; a.bspec = inv ? z->bspec_i : z->bspec_f;
     a.c1 = c1; a.dt = dt; a.t_start = t_start; a.scale = scale; a.c1k = z->c1k; a.c2k = z->c2k;
+    a.max_out = (inv && epi == 2) ? max_out : nullptr;
     if (src_ld != z->in_ld || u_ld != z->u_ld || dst_ld != z->out_ld) return hipErrorInvalidValue;   // tables are per pitch
     a.off0in = (unsigned)(P * src_ld * sizeof(cf)); a.off0u = (unsigned)(P * u_ld * sizeof(cf));
     a.pitch_u = (unsigned)(u_ld * sizeof(cf)); a.pitch_out = (unsigned)(dst_ld * sizeof(cf));

@@ -41,6 +41,9 @@ __host__ __device__ inline int range_row(const RangeArgs& a, int line) {
     return a.row_inner ? a.row0 + line % a.row_inner + (line / a.row_inner) * a.row_stride : line;
 }
 
+// max |image| slot of sarx_csa_plan_set_max_slot: MAX_SHARDS partial maxima, one per 128-byte line (32 floats apart)
+constexpr unsigned MAX_SHARDS = 256;
+constexpr size_t MAX_SLOT_BYTES = MAX_SHARDS * 32 * sizeof(float);
 struct AzArgs {
     const float2* in;
     float2* out;
@@ -56,6 +59,7 @@ struct AzArgs {
     bool nt;              // nontemporal image loads / stores (images too large to be re-read from cache before they are evicted)
     float* look_part;     // SCALE_LOOK: [n_az x n_rg/look] row-wise partial sums of |x|^2 over `look` columns (a power of two <= tile width)
     int look;
+    unsigned* max_out;    // SCALE / SCALE_LOOK: [MAX_SHARDS x 32] bits of partial maxima of |x| over the image as written (hypotf; non-negative floats order like their bits); NULL = off
     int valid_len;        // TWCOL / PROCOL (split lines): only the first valid_len samples of a line are read (rest = 0) / written; 0 = all
     double dt, t_start;
     float scale;          // 1/n_az for the inverse's last step
@@ -109,6 +113,7 @@ struct PfaArgs {
     float scale;                                       // inverse: 1/7199
     int c1k, c2k;                                      // output map k = (c1k k1 + c2k k2) mod 7199
     bool nt;                                           // nontemporal image loads / stores
+    unsigned* max_out;                                 // inverse epilogue: [MAX_SHARDS x 32] partial maxima of |out| (AzArgs::max_out); NULL = off
 };
 struct AzPfa;
 bool az_pfa_supported(int n_az);
@@ -118,7 +123,7 @@ void az_pfa_destroy(AzPfa* z);
 // epi: 0 none, 1 times Phi_1 (forward), 2 times scale (inverse).  src may equal dst; u is a [7199 x u_ld] work array
 hipError_t az_pfa_run(const AzPfa* z, bool inv, const float2* src, size_t src_ld, int src_cols, float2* u, size_t u_ld,
                       float2* dst, size_t dst_ld, int dst_cols, int epi, const double2* c1, double dt, double t_start,
-                      float scale, hipStream_t st);
+                      float scale, hipStream_t st, unsigned* max_out = nullptr);
 
 // products.hip
 struct AtiArgs {
@@ -136,6 +141,8 @@ struct AtiArgs {
     float* ph2;
     float* dpca_phase;
     bool nt;              // nontemporal loads of the two images (their last use)
+    const float* thr_max; // masked variant: ati_phase gets phase where |slc1| > mask_frac * max(thr_max shards), 0 elsewhere (:447-449); NULL = plain
+    float mask_frac;
     float* part_max;      // [blocks]
     double2* part_sum;    // [blocks]
 };

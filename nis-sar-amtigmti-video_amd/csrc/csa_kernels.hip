@@ -246,6 +246,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
         }
     stockham_run<R, W, INV, false>(v, t, c, lds, a.tw_r);
     constexpr int RL = E::R_last;
+    float vmax = 0.f;
 #pragma unroll
     for (int b = 0; b < P / RL; ++b)
 #pragma unroll
@@ -268,6 +269,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                 x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
             } else if constexpr (EPI == AZ_EPI_SCALE_LOOK) {
                 x.x *= a.scale; x.y *= a.scale;
+                if (a.max_out) vmax = fmaxf(vmax, hypotf(x.x, x.y));
                 // |x|^2 summed over the `look` consecutive columns of this row (consecutive lanes): fixed xor tree, bitwise
                 // reproducible; the lane of the group's first column stores the row-wise partial
                 float pw = fmaf(x.x, x.x, x.y * x.y);
@@ -278,6 +280,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                     if (a.valid_len && m * a.n_rg + col >= a.valid_len) continue;
                 }
                 x.x *= a.scale; x.y *= a.scale;
+                if constexpr (EPI == AZ_EPI_SCALE) { if (a.max_out) vmax = fmaxf(vmax, hypotf(x.x, x.y)); }
             } else if constexpr (EPI == AZ_EPI_SCALE_ROWSOUT) {
                 if (rowo >= (size_t)a.io_rows) continue;
                 x.x *= a.scale; x.y *= a.scale;
@@ -301,6 +304,17 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             }
             st_stream(a.out + rowo * a.n_rg + col, x, a.nt);
         }
+    if constexpr (EPI == AZ_EPI_SCALE || EPI == AZ_EPI_SCALE_LOOK) {
+        // max |image| for the 5 % mask of the ATI products (sar_ati_dcpa_sim_csa.py:447), taken while the image is written so
+        // that the ATI launch can mask in the same pass: the same hypotf of the same floats that launch computes
+        if (a.max_out) {
+            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+            // one device-scope atomic per wave on ONE address costs ~11 ns each, serialised (65 536 of them at 8192^2 = 0.7 ms):
+            // 256 shards, one 128-byte line each, maxed again by the consumer
+            if ((threadIdx.x & 63) == 0)
+                atomicMax(a.max_out + 32u * ((blockIdx.x * 7u + blockIdx.y * 13u + (threadIdx.x >> 6)) & (MAX_SHARDS - 1u)), __float_as_uint(vmax));
+        }
+    }
 }
 
 template <int R, int W, bool INV, int EPI> static hipError_t launch_az_one(const AzArgs& a, int nq, hipStream_t st) {

@@ -15,6 +15,8 @@ GeneralCsa* general_csa_create(int n_az, int n_rg, const sarx_radar_params* prm,
                                bool csa_tables = true, int cus = 0);
 void general_csa_destroy(GeneralCsa* g);
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st);
+// max |image| slot ([MAX_SHARDS x 32] floats, AzArgs::max_out) filled by every later focus; false = this plan's route has no such epilogue
+bool general_csa_set_max_slot(GeneralCsa* g, unsigned* slot);
 uint64_t general_csa_bytes(const GeneralCsa* g);
 // one range pass (RangeMode) on a dense [n_az x n_rg] image; hipErrorNotSupported unless the range extent has a direct
 // mixed-radix line kernel (range_mixed.hip)

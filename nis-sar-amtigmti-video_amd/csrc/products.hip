@@ -57,6 +57,20 @@ template <bool OPT> __global__ __launch_bounds__(ATI_THREADS) void ati_dpca_kern
     double sre = 0.0, sim = 0.0;
     const float4* s1 = reinterpret_cast<const float4*>(a.s1);
     const float4* s2 = reinterpret_cast<const float4*>(a.s2);
+    // masked variant: max |slc1| is already known (the focus emitted it), thr = float32 product as the host facade computes it
+    const bool masked = a.thr_max != nullptr;
+    float thr = -1.f;
+    if (masked) {                                        // max over the MAX_SHARDS partial maxima the focus left (one per 128-byte line)
+        __shared__ float s_thr[ATI_THREADS / 64];
+        float m = 0.f;
+        for (unsigned k = threadIdx.x; k < MAX_SHARDS; k += ATI_THREADS) m = fmaxf(m, a.thr_max[32 * k]);
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if ((threadIdx.x & 63) == 0) s_thr[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = s_thr[0];
+        for (int k = 1; k < ATI_THREADS / 64; ++k) m = fmaxf(m, s_thr[k]);
+        thr = m * a.mask_frac;
+    }
     for (size_t i = (size_t)blockIdx.x * ATI_THREADS + threadIdx.x; i < nquad; i += stride) {
         const float4 x0 = ld4(s1 + 2 * i, a.nt), x1 = ld4(s1 + 2 * i + 1, a.nt), y0 = ld4(s2 + 2 * i, a.nt), y1 = ld4(s2 + 2 * i + 1, a.nt);
         Pix p[4];
@@ -64,6 +78,10 @@ template <bool OPT> __global__ __launch_bounds__(ATI_THREADS) void ati_dpca_kern
         ati_pixel<OPT>(make_float2(x0.z, x0.w), make_float2(y0.z, y0.w), a.cal_c, a.cal_s, p[1]);
         ati_pixel<OPT>(make_float2(x1.x, x1.y), make_float2(y1.x, y1.y), a.cal_c, a.cal_s, p[2]);
         ati_pixel<OPT>(make_float2(x1.z, x1.w), make_float2(y1.z, y1.w), a.cal_c, a.cal_s, p[3]);
+        if (masked) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k].phase = p[k].m1 > thr ? p[k].phase : 0.f;
+        }
         reinterpret_cast<float4*>(a.ati_phase)[i] = make_float4(p[0].phase, p[1].phase, p[2].phase, p[3].phase);
         reinterpret_cast<float4*>(a.mag1)[i] = make_float4(p[0].m1, p[1].m1, p[2].m1, p[3].m1);
         reinterpret_cast<float4*>(a.dpca_mag)[i] = make_float4(p[0].dm, p[1].dm, p[2].dm, p[3].dm);
@@ -92,6 +110,7 @@ template <bool OPT> __global__ __launch_bounds__(ATI_THREADS) void ati_dpca_kern
         const size_t i = nquad * 4 + threadIdx.x;
         Pix p;
         ati_pixel<OPT>(a.s1[i], a.s2[i], a.cal_c, a.cal_s, p);
+        if (masked) p.phase = p.m1 > thr ? p.phase : 0.f;
         a.ati_phase[i] = p.phase; a.mag1[i] = p.m1; a.dpca_mag[i] = p.dm;
         if (OPT) {
             if (a.interf) a.interf[i] = p.interf;

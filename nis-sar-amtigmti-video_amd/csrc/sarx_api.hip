@@ -120,6 +120,7 @@ struct sarx_plan {
     int look = 0;          // > 0: the last azimuth launch also writes row-wise |x|^2 partials and a finish launch turns them into look_slot
     float* look_slot = nullptr;   // caller's [n_az/look x n_rg/look] fp32 slot (device)
     float* look_part = nullptr;   // [n_az x n_rg/look], owned by the plan
+    float* max_slot = nullptr;         // sarx_csa_plan_set_max_slot: device float that receives max |image| of every focus
     bool az_nt = false;    // azimuth tile launches use nontemporal accesses (images >= 512 MiB; SARX_AZ_NT=0/1 overrides)
     int slab_tiles = 0;    // > 0: slab mode of sarx_csa_focus_dev with this many azimuth tiles per group (SARX_SLAB_MIB)
     double2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr;
@@ -478,6 +479,14 @@ int sarx_csa_plan_set_look_slot(sarx_plan* p, int looks, float* d_slot) {
     return SARX_OK;
 }
 
+int sarx_csa_plan_set_max_slot(sarx_plan* p, float* d_max) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    if (p->gen && !general_csa_set_max_slot(p->gen, reinterpret_cast<unsigned*>(d_max)))
+        return fail(p->ctx, SARX_ERR_UNSUPPORTED, "the fused maximum exists for power-of-two plans and 7199 x 13200 (sarx_ati_dpca_dev reduces it otherwise)");
+    p->max_slot = d_max;
+    return SARX_OK;
+}
+
 int sarx_csa_plan_bytes(const sarx_plan* p, uint64_t* out) {
     if (!p || !out) return fail(p ? p->ctx : nullptr, SARX_ERR_INVALID, "NULL argument");
     *out = p->bytes;
@@ -551,6 +560,7 @@ static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, v
         a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
         const bool look = inv && p->look_slot;
         if (look) { a.look_part = p->look_part; a.look = p->look; }
+        if (inv) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);
         HIPCHK(c, launch_az_tile(S, p->az_w, inv, inv ? (look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, nq, c->stream));
     }
     return SARX_OK;
@@ -581,6 +591,7 @@ static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out)
         a.in_q_stride = 0; a.in_m_stride = 1; a.out_q_stride = 0; a.out_m_stride = 1;
         const bool look = inv && p->look_slot;
         if (look) { a.look_part = p->look_part; a.look = p->look; }
+        if (inv) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);
         HIPCHK(c, launch_az_tile(n, p->az_w, inv, inv ? (look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, 1, c->stream));
         return SARX_OK;
     }
@@ -620,6 +631,7 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
         case SARX_PASS_AZ_IFFT:
             if (d_in == d_out || d_in == p->buf_b || d_out == p->buf_b)
                 return fail(c, SARX_ERR_INVALID, "azimuth passes are out-of-place");
+            if (p->max_slot && pass_id == SARX_PASS_AZ_IFFT) HIPCHK(c, hipMemsetAsync(p->max_slot, 0, MAX_SLOT_BYTES, c->stream));
             return az_pass(p, pass_id == SARX_PASS_AZ_IFFT, d_in, p->buf_b, d_out);
         case SARX_PASS_RG_FFT_PHI2: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FFT_PHI2, a)); return SARX_OK; }
         case SARX_PASS_RG_IFFT_PHI3: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_IFFT_PHI3, a)); return SARX_OK; }
@@ -637,6 +649,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     if (!d_phist || !d_image || d_phist == d_image) return fail(c, SARX_ERR_INVALID, "image pointers NULL or aliased");
     const bool rg_major = p->flags & SARX_OUT_RG_MAJOR;
     int rc;
+    if (p->max_slot) HIPCHK(c, hipMemsetAsync(p->max_slot, 0, MAX_SLOT_BYTES, c->stream));
     if (p->gen) {
         float2* dst = rg_major ? p->buf_a : (float2*)d_image;
         HIPCHK(c, general_csa_focus(p->gen, (const float2*)d_phist, dst, c->stream));
@@ -793,8 +806,20 @@ int sarx_rda_axes(const sarx_rda_plan* p, double* range_centered, double* cross_
 }
 
 // ---- ATI / DPCA ------------------------------------------------------------------
+static int ati_dpca_impl(sarx_ctx* c, const void* s1, const void* s2, size_t n, double cal_phase, const sarx_ati_outputs* o,
+                         double* max_mag, double* sum2, const float* d_max, float mask_frac);
 int sarx_ati_dpca_dev(sarx_ctx* c, const void* s1, const void* s2, size_t n, double cal_phase,
                       const sarx_ati_outputs* o, double* max_mag, double* sum2) {
+    return ati_dpca_impl(c, s1, s2, n, cal_phase, o, max_mag, sum2, nullptr, 0.f);
+}
+int sarx_ati_dpca_masked_dev(sarx_ctx* c, const void* s1, const void* s2, size_t n, double cal_phase, const float* d_max,
+                             float mask_frac, const sarx_ati_outputs* o) {
+    NEED_CTX(c);
+    if (!d_max) return fail(c, SARX_ERR_INVALID, "d_max is NULL (sarx_csa_plan_set_max_slot provides it)");
+    return ati_dpca_impl(c, s1, s2, n, cal_phase, o, nullptr, nullptr, d_max, mask_frac);
+}
+static int ati_dpca_impl(sarx_ctx* c, const void* s1, const void* s2, size_t n, double cal_phase, const sarx_ati_outputs* o,
+                         double* max_mag, double* sum2, const float* d_max, float mask_frac) {
     NEED_CTX(c);
     if (!s1 || !s2 || !o || !o->ati_phase || !o->slc1_mag || !o->dpca_mag) return fail(c, SARX_ERR_INVALID, "NULL required pointer");
     if (n == 0) { if (max_mag) *max_mag = 0; if (sum2) sum2[0] = sum2[1] = 0; return SARX_OK; }
@@ -811,6 +836,7 @@ int sarx_ati_dpca_dev(sarx_ctx* c, const void* s1, const void* s2, size_t n, dou
     a.interf = (float2*)o->ati_interf; a.diff = (float2*)o->dpca_diff;
     a.mag2 = o->slc2_mag; a.ph1 = o->slc1_phase; a.ph2 = o->slc2_phase; a.dpca_phase = o->dpca_phase;
     a.part_max = c->ati_part_max; a.part_sum = c->ati_part_sum;
+    a.thr_max = d_max; a.mask_frac = mask_frac;
     // the two images are read for the last time here: nontemporal loads once they are too large to still be cached
     // (0.341 -> 0.329 ms at 8192^2); SARX_ATI_NT=0/1 overrides
     { static const int nt = [] { const char* e = getenv("SARX_ATI_NT"); return e ? atoi(e) : -1; }(); a.nt = nt < 0 ? n >= ((size_t)1 << 25) : nt != 0; }

@@ -12,6 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SARX_LIB") or os.path.join(_HERE, "libsarx.so")
 
+MAX_SLOT_BYTES = 32768          # SARX_MAX_SLOT_BYTES: 256 partial maxima, 32 floats apart
 COMM_ID_BYTES = 128
 OUT_AZ_MAJOR, OUT_RG_MAJOR, FUSE_RANGE = 0, 1, 2
 PASS_AZ_FFT_PHI1, PASS_RG_FFT_PHI2, PASS_RG_IFFT_PHI3, PASS_AZ_IFFT, PASS_RG_FUSED_23 = 1, 2, 3, 4, 23
@@ -76,6 +77,7 @@ SIGNATURES = {
     "sarx_csa_pass": (_i, [_vp, _i, _vp, _vp]),
     "sarx_csa_plan_mark_range": (_i, [_vp, _i, _i]),
     "sarx_csa_plan_set_look_slot": (_i, [_vp, _i, _vp]),
+    "sarx_csa_plan_set_max_slot": (_i, [_vp, _vp]),
     "sarx_csa_plan_bytes": (_i, [_vp, _P(_u64)]),
     "sarx_rda_plan_create": (_i, [_vp, _i, _i, _P(RadarParams), _P(_vp)]),
     "sarx_rda_plan_destroy": (_i, [_vp]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "sarx_rda_axes": (_i, [_vp, _vp, _vp, _vp]),
     "sarx_ati_dpca_dev": (_i, [_vp, _vp, _vp, _sz, _d, _P(AtiOutputs), _P(_d), _P(_d)]),
     "sarx_ati_stats": (_i, [_vp, _P(_d), _P(_d)]),
+    "sarx_ati_dpca_masked_dev": (_i, [_vp, _vp, _vp, _sz, _d, _vp, _f, _P(AtiOutputs)]),
     "sarx_mask_phase_frac_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
     "sarx_magnitude_dev": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_mask_phase_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),

@@ -190,7 +190,7 @@ class TwoChannelBatch:
     """
 
     def __init__(self, ctx, n, n_frames, world=1, rank=0, stack="multilook", looks=16, rccl=False, host_comm=None,
-                 seed_base=1000, flags=None, mask_frac=0.05, resident=True):
+                 seed_base=1000, flags=None, mask_frac=0.05, resident=True, fused_mask=True):
         from . import _ffi, radar
         from .engine import CsaPlan
         if stack not in STACKS:
@@ -206,6 +206,10 @@ class TwoChannelBatch:
         self.s1, self.s2 = ctx.alloc(px * 8), ctx.alloc(px * 8)
         self.outs = {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
         self.masked = ctx.alloc(px * 4)
+        # the 5 % mask inside the ATI launch: channel 1's focus leaves max|slc1| in d_max while it writes the image
+        # (sarx_csa_plan_set_max_slot), so no further pass over the phase and magnitude planes is needed
+        self.fused_mask = bool(fused_mask)
+        self.d_max = ctx.alloc(_ffi.MAX_SLOT_BYTES)
         self.slot_shape = (n // looks, n // looks) if stack == "multilook" else (n, n)
         self.slot_bytes = self.slot_shape[0] * self.slot_shape[1] * 4
         self.n_rounds = rounds(self.n_frames, self.world)
@@ -240,12 +244,20 @@ class TwoChannelBatch:
         fused = slot_ptr is not None and self.stack_kind == "multilook"
         if fused:
             self.plan.set_look_slot(self.looks, slot_ptr)
+        if self.fused_mask:
+            self.plan.set_max_slot(self.d_max)
         self.plan.focus_dev(bufs[0], self.s1)
         if fused:
             self.plan.set_look_slot(self.looks, None)
+        if self.fused_mask:
+            self.plan.set_max_slot(None)
         self.plan.focus_dev(bufs[1], self.s2)
-        ctx.ati_dpca(self.s1, self.s2, self.px, 0.0, self.outs, want_stats=False)
-        ctx.mask_phase_frac(self.outs["ati_phase"], self.outs["slc1_mag"], self.px, self.mask_frac, self.masked)
+        if self.fused_mask:
+            outs = dict(self.outs, ati_phase=self.masked)          # the phase plane comes out masked; no unmasked copy is kept
+            ctx.ati_dpca_masked(self.s1, self.s2, self.px, 0.0, self.d_max, self.mask_frac, outs)
+        else:
+            ctx.ati_dpca(self.s1, self.s2, self.px, 0.0, self.outs, want_stats=False)
+            ctx.mask_phase_frac(self.outs["ati_phase"], self.outs["slc1_mag"], self.px, self.mask_frac, self.masked)
 
     def _slot_ptr(self, i, r):
         return self.d_stack.ptr + (i * self.world + r) * self.slot_bytes

@@ -206,6 +206,16 @@ class Context:
                                          C.byref(mx) if want_stats else None, sm if want_stats else None), self.h)
         return (mx.value, complex(sm[0], sm[1])) if want_stats else None
 
+    def ati_dpca_masked(self, slc1, slc2, n, cal_phase, d_max, mask_frac, outs):
+        """The same launch with the magnitude mask applied on the way out: outs['ati_phase'] receives the masked phase
+        (sar_ati_dcpa_sim_csa.py:447-449); d_max = device float holding max|slc1| (CsaPlan.set_max_slot).  Only enqueues."""
+        o = _ffi.AtiOutputs()
+        for k, _ in _ffi.AtiOutputs._fields_:
+            b = outs.get(k)
+            setattr(o, k, b.ptr if b is not None else None)
+        check(self.lib.sarx_ati_dpca_masked_dev(self.h, slc1.ptr, slc2.ptr, int(n), float(cal_phase), d_max.ptr, float(mask_frac),
+                                                C.byref(o)), self.h)
+
     # -- RCCL --
     @staticmethod
     def rccl_info():
@@ -298,6 +308,11 @@ class CsaPlan:
         """Every later focus_dev also writes the looks x looks multilook of |image|^2 to the device address slot_ptr
         (None / 0 switches it off): the VideoSAR stack slot without reading the image again."""
         check(self.ctx.lib.sarx_csa_plan_set_look_slot(self.h, int(looks), slot_ptr if slot_ptr else None), self.ctx.h)
+
+    def set_max_slot(self, d_max):
+        """Every later focus_dev also leaves max|image| (fp32) in the device buffer d_max (None switches it off): the threshold
+        input of Context.ati_dpca_masked without a further pass over the image."""
+        check(self.ctx.lib.sarx_csa_plan_set_max_slot(self.h, d_max.ptr if d_max is not None else None), self.ctx.h)
 
     def focus_dev(self, d_phist, d_image):
         check(self.ctx.lib.sarx_csa_focus_dev(self.h, d_phist.ptr, d_image.ptr), self.ctx.h)

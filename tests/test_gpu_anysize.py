@@ -133,14 +133,25 @@ def test_native_scene_size_vs_oracle():
     px = n_az * n_rg
     d_in, d_out = ctx.alloc(px * 8), ctx.alloc(px * 8)
     ctx.fill_noise(d_in, px, 7199)
+    from sarx import _ffi
+    d_max = ctx.alloc(_ffi.MAX_SLOT_BYTES)                           # sarx_csa_plan_set_max_slot on the prime-factor route
+    plan.set_max_slot(d_max)
     plan.focus_dev(d_in, d_out)
+    plan.set_max_slot(None)
     raw = d_in.download(np.complex64, (n_az, n_rg))
     img = d_out.download(np.complex64, (n_az, n_rg))
+    shards = d_max.download(np.float32, (256, 32))
+    assert not shards[:, 1:].any()
+    assert abs(float(shards[:, 0].max()) - float(np.abs(img).max())) <= 2e-7 * float(np.abs(img).max())
     ref = orc.sar_focus_csa_lean(raw, *args, workers=8, block=64)[0]
     assert orc.rel_l2(img.T, ref) < TOL
     assert orc.rel_l2(np.abs(img.T), np.abs(ref)) < TOL
-    d_in.release()
-    d_out.release()
+    plan2 = sarx.CsaPlan(ctx, 100, 13200, *args)                     # chirp-z azimuth route: no such epilogue, and it says so
+    with pytest.raises(sarx.SarxError):
+        plan2.set_max_slot(d_max)
+    plan2.close()
+    for b in (d_in, d_out, d_max):
+        b.release()
     plan.close()
 
 

@@ -253,6 +253,47 @@ def test_fused_look_slot(sx, ctx, n_az, n_rg, looks):
     plan.close()
 
 
+@pytest.mark.parametrize("n_az,n_rg", [(512, 1024), (64, 128), (2048, 256)])
+def test_fused_max_and_masked_ati(sx, ctx, n_az, n_rg):
+    """sarx_csa_plan_set_max_slot + sarx_ati_dpca_masked_dev: max|image| emitted by the focus equals the maximum the ATI launch
+    reduces from the finished image (same hypotf of the same floats), and the phase plane masked inside the ATI launch equals
+    ATI + mask as two launches, bit for bit (sar_ati_dcpa_sim_csa.py:414-419, 447-449)."""
+    from sarx import _ffi
+    raw, k = orc.point_scene(n_az, n_rg, seed=n_az + 3, clutter_db=-10.0)
+    args = orc.focus_args(k)
+    plan = _plan(sx, ctx, n_az, n_rg, args, flags=_ffi.FUSE_RANGE)
+    px = n_az * n_rg
+    d_in, d_in2 = ctx.to_device(raw), ctx.to_device(np.roll(raw, 1, axis=0) * np.complex64(0.9 + 0.1j))
+    s1, s2 = ctx.alloc(px * 8), ctx.alloc(px * 8)
+    d_max = ctx.alloc(_ffi.MAX_SLOT_BYTES)
+    ctx.lib.sarx_memset(ctx.h, d_max.ptr, 0xFF, _ffi.MAX_SLOT_BYTES)  # stale contents must not survive
+    plan.set_max_slot(d_max)
+    plan.focus_dev(d_in, s1)
+    plan.set_max_slot(None)
+    plan.focus_dev(d_in2, s2)                                        # must not touch d_max
+    img = s1.download(np.complex64, (n_az, n_rg))
+    shards = d_max.download(np.float32, (256, 32))
+    assert not shards[:, 1:].any()
+    got_max = shards[:, 0].max()
+    outs = {kk: ctx.alloc(px * 4) for kk in ("ati_phase", "slc1_mag", "dpca_mag")}
+    mx, _ = ctx.ati_dpca(s1, s2, px, 0.0, outs)
+    assert np.float32(mx) == got_max and got_max > 0
+    assert abs(float(got_max) - np.abs(img).max()) <= 2e-7 * float(got_max)
+    two = ctx.alloc(px * 4)
+    ctx.mask_phase_frac(outs["ati_phase"], outs["slc1_mag"], px, 0.05, two)
+    ref = {kk: outs[kk].download(np.float32, (px,)) for kk in ("slc1_mag", "dpca_mag")}
+    ref_masked = two.download(np.float32, (px,))
+    assert 0 < np.count_nonzero(ref_masked) < px                     # the mask does something
+    outs2 = {kk: ctx.alloc(px * 4) for kk in ("ati_phase", "slc1_mag", "dpca_mag")}
+    ctx.ati_dpca_masked(s1, s2, px, 0.0, d_max, 0.05, outs2)
+    np.testing.assert_array_equal(outs2["ati_phase"].download(np.float32, (px,)), ref_masked)
+    for kk in ref:
+        np.testing.assert_array_equal(outs2[kk].download(np.float32, (px,)), ref[kk])
+    mx2, sm2 = ctx.ati_stats()
+    assert mx2 == mx
+    plan.close()
+
+
 def test_errors_are_loud(sx, ctx):
     k = orc.scaled_radar(64, 64)
     with pytest.raises(sx.SarxError):
