@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 201
+#define SARX_VERSION 202
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -141,6 +141,18 @@ int sarx_csa_plan_set_look_slot(sarx_plan* plan, int looks, float* d_slot);
  * sarx_ati_dpca_masked_dev can apply the 5 % mask (sar_ati_dcpa_sim_csa.py:447-449) in the ATI pass itself instead of a further
  * pass over two planes.  Power-of-two plans and the native 7199 x 13200; d_max = NULL switches it off. */
 int sarx_csa_plan_set_max_slot(sarx_plan* plan, float* d_max);
+/* ATI / DPCA products fused into the focus of the SECOND channel: while d_slc1 is set, the last azimuth launch of every
+ * sarx_csa_focus_dev of this plan reads slc1 = d_slc1 [n_az x n_rg] beside the samples of slc2 it is about to write and emits
+ * ati_phase (masked: 0 where |slc1| <= mask_frac * max|slc1|, :447-449), |slc1| and |slc1 - slc2 e^(i cal)| (:414-419) as
+ * [n_az x n_rg] fp32 planes - bit for bit what sarx_ati_dpca_masked_dev computes from the two finished images, without writing
+ * slc2 and reading both images again (keep_image != 0 also writes slc2 to d_image as usual; d_image is needed as scratch either
+ * way).  d_max: the SARX_MAX_SLOT_BYTES slot of the plan that focused slc1.  sarx_ati_stats afterwards returns max|slc1| and the
+ * phase-balance sum (fixed-order reduction: reproducible; not bit-identical to the separate launch's order of additions).
+ * Power-of-two plans in the default image layout (n_rg a multiple of 64, or the last azimuth launch's tiles whole waves); takes
+ * precedence over a look slot.
+ * d_slc1 = NULL switches it off. */
+int sarx_csa_plan_set_ati(sarx_plan* plan, const void* d_slc1, const float* d_max, float mask_frac, double cal_phase,
+                          float* d_ati_phase_masked, float* d_slc1_mag, float* d_dpca_mag, int keep_image);
 /* bytes of HBM scratch the plan holds (two ping-pong images + tables) */
 int sarx_csa_plan_bytes(const sarx_plan* plan, uint64_t* out_bytes);
 

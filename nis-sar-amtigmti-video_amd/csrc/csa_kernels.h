@@ -17,7 +17,8 @@ enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_S
                   AZ_EPI_SCALE_ROWSOUT = 10,
                   AZ_EPI_CROPOUT_PHI1 = 11,
                   AZ_EPI_CROPOUT_MAG = 12,
-                  AZ_EPI_SCALE_LOOK = 13 };     // SCALE, and the row's sums of |x|^2 over `look` consecutive columns go to look_part (VideoSAR stack slot fused into the focus)    // CROPOUT, but the magnitude goes to out_mag (fp32) instead of the complex value to out   // CROPOUT, then * Phi_1(output row, col): the forward azimuth chirp-z ends in the CSA's first phase  // SCALE, but output rows >= io_rows are not written (only the cropped part is used)       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
+                  AZ_EPI_SCALE_LOOK = 13,
+                  AZ_EPI_SCALE_ATI = 14 };    // SCALE, and the ATI / DPCA products of (ati_s1, this image) go out instead of (or beside) the image     // SCALE, and the row's sums of |x|^2 over `look` consecutive columns go to look_part (VideoSAR stack slot fused into the focus)    // CROPOUT, but the magnitude goes to out_mag (fp32) instead of the complex value to out   // CROPOUT, then * Phi_1(output row, col): the forward azimuth chirp-z ends in the CSA's first phase  // SCALE, but output rows >= io_rows are not written (only the cropped part is used)       // outputs * rowvec[output row] * scale, written to a [io_rows x io_cols] array (ld io_ld) only inside it
 
 struct RangeArgs {
     const float2* in;
@@ -59,6 +60,10 @@ struct AzArgs {
     bool nt;              // nontemporal image loads / stores (images too large to be re-read from cache before they are evicted)
     float* look_part;     // SCALE_LOOK: [n_az x n_rg/look] row-wise partial sums of |x|^2 over `look` columns (a power of two <= tile width)
     int look;
+    // SCALE_ATI: slc1 = ati_s1 [n_az x n_rg], slc2 = this launch's output; masked phase, |slc1|, |slc1 - slc2 e^(i cal)| planes; partial sums of
+    // slc1 conj(slc2) per wave ([tiles x waves], fixed order: reproducible); threshold ati_frac * max over the MAX_SHARDS shards of ati_thr
+    const float2* ati_s1; float *ati_phase, *ati_m1, *ati_dm; double2* ati_part; const float* ati_thr;
+    float ati_cc, ati_cs, ati_frac; int ati_keep_image;
     unsigned* max_out;    // SCALE / SCALE_LOOK: [MAX_SHARDS x 32] bits of partial maxima of |x| over the image as written (hypotf; non-negative floats order like their bits); NULL = off
     int valid_len;        // TWCOL / PROCOL (split lines): only the first valid_len samples of a line are read (rest = 0) / written; 0 = all
     double dt, t_start;
@@ -149,6 +154,8 @@ struct AtiArgs {
 int ati_blocks(size_t n);
 hipError_t launch_ati_dpca(const AtiArgs& a, hipStream_t st);
 hipError_t launch_ati_finish(const float* part_max, const double2* part_sum, int blocks, double* out3, hipStream_t st);
+// scratch: 128 double2 (the first level's results)
+hipError_t launch_ati_finish_sums(const double2* part_sum, int n, const float* max_shards, double2* scratch, double* out3, hipStream_t st);
 hipError_t launch_mask_phase(const float* phase, const float* mag, size_t n, float thr, float* out, hipStream_t st);
 // thr = frac * out3[0] on the device (out3 = {max|slc1|, sum re, sum im} of the last ATI launch)
 hipError_t launch_mask_phase_frac(const float* phase, const float* mag, size_t n, float frac, const double* out3, float* out,

@@ -5,6 +5,7 @@
 #include "csa_kernels.h"
 #include "fft_core.hpp"
 #include "phase.hpp"
+#include "ati_pixel.hpp"
 
 namespace sarx {
 
@@ -244,6 +245,19 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             }
             v[b * R0 + r] = x;
         }
+    float ati_thr = 0.f;
+    double ati_re = 0.0, ati_im = 0.0;
+    if constexpr (EPI == AZ_EPI_SCALE_ATI) {       // mask threshold: max over the shards channel 1's focus left
+        __shared__ float s_m[AzCfg<R, W>::THREADS / 64 > 0 ? AzCfg<R, W>::THREADS / 64 : 1];
+        float m = 0.f;
+        for (unsigned k = threadIdx.x; k < MAX_SHARDS; k += AzCfg<R, W>::THREADS) m = fmaxf(m, a.ati_thr[32 * k]);
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = s_m[0];
+        for (int k = 1; k < AzCfg<R, W>::THREADS / 64; ++k) m = fmaxf(m, s_m[k]);
+        ati_thr = m * a.ati_frac;
+    }
     stockham_run<R, W, INV, false>(v, t, c, lds, a.tw_r);
     constexpr int RL = E::R_last;
     float vmax = 0.f;
@@ -267,6 +281,16 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
 #endif
             } else if constexpr (EPI == AZ_EPI_PHI1) {
                 x = cmul(x, phi1(col, a.c1[rowo], a.dt, a.t_start));
+            } else if constexpr (EPI == AZ_EPI_SCALE_ATI) {
+                x.x *= a.scale; x.y *= a.scale;
+                const size_t o = rowo * a.n_rg + col;
+                Pix px;
+                ati_pixel<false>(a.ati_s1[o], x, a.ati_cc, a.ati_cs, px);
+                a.ati_phase[o] = px.m1 > ati_thr ? px.phase : 0.f;         // (:447-449)
+                a.ati_m1[o] = px.m1;
+                a.ati_dm[o] = px.dm;
+                ati_re += px.sre; ati_im += px.sim;
+                if (!a.ati_keep_image) continue;
             } else if constexpr (EPI == AZ_EPI_SCALE_LOOK) {
                 x.x *= a.scale; x.y *= a.scale;
                 if (a.max_out) vmax = fmaxf(vmax, hypotf(x.x, x.y));
@@ -304,6 +328,11 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             }
             st_stream(a.out + rowo * a.n_rg + col, x, a.nt);
         }
+    if constexpr (EPI == AZ_EPI_SCALE_ATI) {
+        for (int off = 32; off > 0; off >>= 1) { ati_re += __shfl_xor(ati_re, off, 64); ati_im += __shfl_xor(ati_im, off, 64); }
+        if ((threadIdx.x & 63) == 0)
+            a.ati_part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (AzCfg<R, W>::THREADS / 64) + (threadIdx.x >> 6)] = make_double2(ati_re, ati_im);
+    }
     if constexpr (EPI == AZ_EPI_SCALE || EPI == AZ_EPI_SCALE_LOOK) {
         // max |image| for the 5 % mask of the ATI products (sar_ati_dcpa_sim_csa.py:447), taken while the image is written so
         // that the ATI launch can mask in the same pass: the same hypotf of the same floats that launch computes
@@ -340,6 +369,7 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_TWIDDLE: return launch_az_one<R, W, true, AZ_EPI_TWIDDLE>(a, nq, st);
             case AZ_EPI_SCALE: return launch_az_one<R, W, true, AZ_EPI_SCALE>(a, nq, st);
             case AZ_EPI_SCALE_LOOK: return launch_az_one<R, W, true, AZ_EPI_SCALE_LOOK>(a, nq, st);
+            case AZ_EPI_SCALE_ATI: if constexpr (AzCfg<R, W>::THREADS % 64 == 0) return launch_az_one<R, W, true, AZ_EPI_SCALE_ATI>(a, nq, st); else return hipErrorInvalidValue;
             case AZ_EPI_PROCOL: return launch_az_one<R, W, true, AZ_EPI_PROCOL>(a, nq, st);
             case AZ_EPI_CROPOUT: return launch_az_one<R, W, true, AZ_EPI_CROPOUT>(a, nq, st);
             case AZ_EPI_SCALE_ROWSOUT: return launch_az_one<R, W, true, AZ_EPI_SCALE_ROWSOUT>(a, nq, st);

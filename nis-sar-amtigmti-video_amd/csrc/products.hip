@@ -3,6 +3,7 @@
 // magnitude mask (:447-449), the LDS corner turn, multilook and noise fill.
 // All are HBM-bound: 16-byte accesses per lane, grid-stride, no MFMA.
 #include "csa_kernels.h"
+#include "ati_pixel.hpp"
 
 namespace sarx {
 
@@ -16,32 +17,6 @@ int ati_blocks(size_t n) {
     if (b > ATI_MAX_BLOCKS) b = ATI_MAX_BLOCKS;
     if (b < 1) b = 1;
     return (int)b;
-}
-
-struct Pix {
-    float phase, m1, dm, m2, p1, p2, dp;
-    cf interf, diff;
-    double sre, sim;
-};
-
-template <bool OPT> __device__ __forceinline__ void ati_pixel(cf a, cf b, float cc, float cs, Pix& o) {
-    // uncalibrated interferogram feeds the phase-balance sum (viewer :249)
-    o.sre = (double)a.x * b.x + (double)a.y * b.y;
-    o.sim = (double)a.y * b.x - (double)a.x * b.y;
-    const cf bc = make_float2(b.x * cc - b.y * cs, b.x * cs + b.y * cc);   // s2 * exp(i cal)  (viewer :43)
-    const cf in = make_float2(fmaf(a.x, bc.x, a.y * bc.y), fmaf(a.y, bc.x, -a.x * bc.y));   // a * conj(bc)  (:414)
-    const cf df = make_float2(a.x - bc.x, a.y - bc.y);                                     // (:418)
-    o.phase = atan2f(in.y, in.x);      // (:415)
-    o.m1 = hypotf(a.x, a.y);           // (:416)
-    o.dm = hypotf(df.x, df.y);         // (:419)
-    o.interf = in;
-    o.diff = df;
-    if (OPT) {
-        o.m2 = hypotf(bc.x, bc.y);
-        o.p1 = atan2f(a.y, a.x);
-        o.p2 = atan2f(bc.y, bc.x);
-        o.dp = atan2f(df.y, df.x);
-    }
 }
 
 typedef float nt_v4f __attribute__((ext_vector_type(4)));
@@ -171,6 +146,47 @@ __global__ void ati_finish_kernel(const float* part_max, const double2* part_sum
         __syncthreads();
     }
     if (threadIdx.x == 0) { out3[0] = (double)smax[0]; out3[1] = sr[0]; out3[2] = si[0]; }
+}
+// the fused form (az_tile_kernel, AZ_EPI_SCALE_ATI): partial sums only, the maximum comes from the focus's shards.  Two fixed-order
+// levels (a single workgroup walking 65 536 partials took 0.10 ms): FIN_BLOCKS workgroups reduce one contiguous chunk each, the last
+// level adds their results in index order; `scratch` holds FIN_BLOCKS double2.
+static constexpr int FIN_BLOCKS = 128;
+__device__ __forceinline__ void block_sum(double& re, double& im, double* sr, double* si) {
+    sr[threadIdx.x] = re; si[threadIdx.x] = im;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sr[threadIdx.x] += sr[threadIdx.x + s]; si[threadIdx.x] += si[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    re = sr[0]; im = si[0];
+}
+__global__ __launch_bounds__(256) void ati_finish_sums1_kernel(const double2* part_sum, int n, double2* scratch) {
+    __shared__ double sr[256], si[256];
+    const int chunk = (n + FIN_BLOCKS - 1) / FIN_BLOCKS, lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    double re = 0.0, im = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) { re += part_sum[i].x; im += part_sum[i].y; }
+    block_sum(re, im, sr, si);
+    if (threadIdx.x == 0) scratch[blockIdx.x] = make_double2(re, im);
+}
+__global__ __launch_bounds__(256) void ati_finish_sums2_kernel(const double2* scratch, const float* max_shards, double* out3) {
+    __shared__ float smax[256];
+    __shared__ double sr[256], si[256];
+    double re = 0.0, im = 0.0;
+    if (threadIdx.x < FIN_BLOCKS) { re = scratch[threadIdx.x].x; im = scratch[threadIdx.x].y; }
+    float m = 0.f;
+    for (unsigned k = threadIdx.x; k < MAX_SHARDS; k += 256) m = fmaxf(m, max_shards[32 * k]);
+    smax[threadIdx.x] = m;
+    block_sum(re, im, sr, si);
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out3[0] = (double)smax[0]; out3[1] = re; out3[2] = im; }
+}
+hipError_t launch_ati_finish_sums(const double2* part_sum, int n, const float* max_shards, double2* scratch, double* out3, hipStream_t st) {
+    hipLaunchKernelGGL(ati_finish_sums1_kernel, dim3(FIN_BLOCKS), dim3(256), 0, st, part_sum, n, scratch);
+    hipLaunchKernelGGL(ati_finish_sums2_kernel, dim3(1), dim3(256), 0, st, (const double2*)scratch, max_shards, out3);
+    return hipGetLastError();
 }
 hipError_t launch_ati_finish(const float* part_max, const double2* part_sum, int blocks, double* out3, hipStream_t st) {
     hipLaunchKernelGGL(ati_finish_kernel, dim3(1), dim3(256), 0, st, part_max, part_sum, blocks, out3);

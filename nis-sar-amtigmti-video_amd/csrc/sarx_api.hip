@@ -120,6 +120,11 @@ struct sarx_plan {
     int look = 0;          // > 0: the last azimuth launch also writes row-wise |x|^2 partials and a finish launch turns them into look_slot
     float* look_slot = nullptr;   // caller's [n_az/look x n_rg/look] fp32 slot (device)
     float* look_part = nullptr;   // [n_az x n_rg/look], owned by the plan
+    // sarx_csa_plan_set_ati: the last azimuth launch emits the ATI / DPCA products of (ati_s1, the image being written)
+    const float2* ati_s1 = nullptr; const float* ati_thr = nullptr; float ati_frac = 0.f; double ati_cal = 0.0;
+    float *ati_phase = nullptr, *ati_m1 = nullptr, *ati_dm = nullptr; int ati_keep_image = 0;
+    double2* ati_part = nullptr; int ati_nparts = 0;
+    int ati_w = 32;                    // tile width of that launch: 64 columns where n_rg allows (256-byte row segments of the fp32 planes)
     float* max_slot = nullptr;         // sarx_csa_plan_set_max_slot: device float that receives max |image| of every focus
     bool az_nt = false;    // azimuth tile launches use nontemporal accesses (images >= 512 MiB; SARX_AZ_NT=0/1 overrides)
     int slab_tiles = 0;    // > 0: slab mode of sarx_csa_focus_dev with this many azimuth tiles per group (SARX_SLAB_MIB)
@@ -448,6 +453,7 @@ int sarx_csa_plan_destroy(sarx_plan* p) {
     hipStreamSynchronize(p->ctx->stream);
     general_csa_destroy(p->gen);
     hipFree(p->c1); hipFree(p->c2); hipFree(p->c3);
+    hipFree(p->ati_part);
     hipFree(p->buf_a); hipFree(p->buf_b); hipFree(p->h_in); hipFree(p->h_out); hipFree(p->look_part);
     delete p;
     return SARX_OK;
@@ -484,6 +490,34 @@ int sarx_csa_plan_set_max_slot(sarx_plan* p, float* d_max) {
     if (p->gen && !general_csa_set_max_slot(p->gen, reinterpret_cast<unsigned*>(d_max)))
         return fail(p->ctx, SARX_ERR_UNSUPPORTED, "the fused maximum exists for power-of-two plans and 7199 x 13200 (sarx_ati_dpca_dev reduces it otherwise)");
     p->max_slot = d_max;
+    return SARX_OK;
+}
+
+int sarx_csa_plan_set_ati(sarx_plan* p, const void* d_slc1, const float* d_max, float mask_frac, double cal_phase,
+                          float* d_ati_phase_masked, float* d_slc1_mag, float* d_dpca_mag, int keep_image) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!d_slc1) { p->ati_s1 = nullptr; return SARX_OK; }
+    if (!d_max || !d_ati_phase_masked || !d_slc1_mag || !d_dpca_mag) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (p->gen || p->n_rg % 32 || (p->flags & SARX_OUT_RG_MAJOR) || p->slab_tiles > 0)
+        return fail(c, SARX_ERR_UNSUPPORTED, "the fused ATI products exist for power-of-two plans in the default image layout (sarx_ati_dpca_dev otherwise)");
+    int w = (p->n_rg % 64 == 0) ? 64 : 32;          // 64 columns where n_rg allows: 256-byte row segments of the fp32 planes
+    if (const char* ev = getenv("SARX_ATI_W")) { const int e = atoi(ev); if ((e == 32 || e == 64) && p->n_rg % e == 0) w = e; }
+    const int tpt = (p->az_s >= 16 ? p->az_s / 16 : 1) * w;        // threads per tile of the last azimuth launch (rows az_s)
+    if (tpt % 64) return fail(c, SARX_ERR_UNSUPPORTED, "n_az=%d n_rg=%d: the last azimuth launch's tiles have %d threads, the fused ATI "
+                                                        "products need whole waves (sarx_ati_dpca_dev otherwise)", p->n_az, p->n_rg, tpt);
+    p->ati_w = w;
+    const int tiles = (p->az_s == p->n_az ? 1 : p->n_az / p->az_s) * (p->n_rg / w);
+    const int waves = tpt / 64;
+    if (!p->ati_part) {
+        hipError_t e = hipMalloc(&p->ati_part, ((size_t)tiles * waves + 128) * sizeof(double2));     // + the finish's first-level results
+        if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc ATI partial sums: %s", hipGetErrorString(e));
+        p->bytes += (size_t)tiles * waves * sizeof(double2);
+    }
+    p->ati_nparts = tiles * waves;
+    p->ati_s1 = (const float2*)d_slc1; p->ati_thr = d_max; p->ati_frac = mask_frac; p->ati_cal = cal_phase;
+    p->ati_phase = d_ati_phase_masked; p->ati_m1 = d_slc1_mag; p->ati_dm = d_dpca_mag; p->ati_keep_image = keep_image != 0;
     return SARX_OK;
 }
 
@@ -538,6 +572,19 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
 // One step of the two-step (four-step) azimuth transform n_az = RA * S over the tiles [q0, q0 + nq):
 //   step A: tile q in [0,S):  rows q + m*S, (I)FFT over m (length RA), twiddle W_n^(-+q*m'), same rows of `out`
 //   step B: tile q in [0,RA): rows q*S + m, (I)FFT over m (length S), rows q + m'*RA of `out` (natural bin order), epilogue
+static void ati_args(const sarx_plan* p, AzArgs& a) {
+    a.ati_s1 = p->ati_s1; a.ati_thr = p->ati_thr; a.ati_frac = p->ati_frac;
+    a.ati_cc = (float)cos(p->ati_cal); a.ati_cs = (float)sin(p->ati_cal);
+    a.ati_phase = p->ati_phase; a.ati_m1 = p->ati_m1; a.ati_dm = p->ati_dm;
+    a.ati_part = p->ati_part; a.ati_keep_image = p->ati_keep_image;
+}
+// the fixed-order finish of the fused ATI products' phase-balance sum, after the last azimuth launch of a focus
+static int ati_finish(sarx_plan* p) {
+    if (!p->ati_s1) return SARX_OK;
+    sarx_ctx* c = p->ctx;
+    HIPCHK(c, launch_ati_finish_sums(p->ati_part, p->ati_nparts, p->ati_thr, p->ati_part + p->ati_nparts, c->ati_out3, c->stream));
+    return SARX_OK;
+}
 static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, void* out, int q0, int nq) {
     sarx_ctx* c = p->ctx;
     const int n = p->n_az, RA = n / S;
@@ -561,7 +608,9 @@ static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, v
         const bool look = inv && p->look_slot;
         if (look) { a.look_part = p->look_part; a.look = p->look; }
         if (inv) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);
-        HIPCHK(c, launch_az_tile(S, p->az_w, inv, inv ? (look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, nq, c->stream));
+        const bool ati = inv && p->ati_s1;
+        if (ati) ati_args(p, a);
+        HIPCHK(c, launch_az_tile(S, ati ? p->ati_w : p->az_w, inv, inv ? (ati ? AZ_EPI_SCALE_ATI : look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, nq, c->stream));
     }
     return SARX_OK;
 }
@@ -592,7 +641,9 @@ static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out)
         const bool look = inv && p->look_slot;
         if (look) { a.look_part = p->look_part; a.look = p->look; }
         if (inv) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);
-        HIPCHK(c, launch_az_tile(n, p->az_w, inv, inv ? (look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, 1, c->stream));
+        const bool ati = inv && p->ati_s1;
+        if (ati) ati_args(p, a);
+        HIPCHK(c, launch_az_tile(n, ati ? p->ati_w : p->az_w, inv, inv ? (ati ? AZ_EPI_SCALE_ATI : look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, 1, c->stream));
         return SARX_OK;
     }
     int rc;
@@ -703,6 +754,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
         if ((rc = az_pass(p, true, p->buf_b, p->buf_b, last)) != SARX_OK) return rc;
     }
     if ((rc = look_finish(p)) != SARX_OK) return rc;
+    if ((rc = ati_finish(p)) != SARX_OK) return rc;
     if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
     return SARX_OK;
 }

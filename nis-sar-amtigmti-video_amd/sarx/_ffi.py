@@ -78,6 +78,7 @@ SIGNATURES = {
     "sarx_csa_plan_mark_range": (_i, [_vp, _i, _i]),
     "sarx_csa_plan_set_look_slot": (_i, [_vp, _i, _vp]),
     "sarx_csa_plan_set_max_slot": (_i, [_vp, _vp]),
+    "sarx_csa_plan_set_ati": (_i, [_vp, _vp, _vp, _f, _d, _vp, _vp, _vp, _i]),
     "sarx_csa_plan_bytes": (_i, [_vp, _P(_u64)]),
     "sarx_rda_plan_create": (_i, [_vp, _i, _i, _P(RadarParams), _P(_vp)]),
     "sarx_rda_plan_destroy": (_i, [_vp]),

@@ -190,7 +190,7 @@ class TwoChannelBatch:
     """
 
     def __init__(self, ctx, n, n_frames, world=1, rank=0, stack="multilook", looks=16, rccl=False, host_comm=None,
-                 seed_base=1000, flags=None, mask_frac=0.05, resident=True, fused_mask=True):
+                 seed_base=1000, flags=None, mask_frac=0.05, resident=True, fused_mask=True, fused_ati=True):
         from . import _ffi, radar
         from .engine import CsaPlan
         if stack not in STACKS:
@@ -209,6 +209,9 @@ class TwoChannelBatch:
         # the 5 % mask inside the ATI launch: channel 1's focus leaves max|slc1| in d_max while it writes the image
         # (sarx_csa_plan_set_max_slot), so no further pass over the phase and magnitude planes is needed
         self.fused_mask = bool(fused_mask)
+        # ... and the ATI / DPCA products out of channel 2's last azimuth launch (sarx_csa_plan_set_ati): slc2 is never written,
+        # neither image is read again; sizes without that epilogue keep the separate launch
+        self.fused_ati = bool(fused_ati) and self.fused_mask and n % 64 == 0
         self.d_max = ctx.alloc(_ffi.MAX_SLOT_BYTES)
         self.slot_shape = (n // looks, n // looks) if stack == "multilook" else (n, n)
         self.slot_bytes = self.slot_shape[0] * self.slot_shape[1] * 4
@@ -251,6 +254,11 @@ class TwoChannelBatch:
             self.plan.set_look_slot(self.looks, None)
         if self.fused_mask:
             self.plan.set_max_slot(None)
+        if self.fused_ati:
+            self.plan.set_ati(self.s1, self.d_max, self.mask_frac, 0.0, self.masked, self.outs["slc1_mag"], self.outs["dpca_mag"])
+            self.plan.focus_dev(bufs[1], self.s2)               # s2 serves as scratch only
+            self.plan.set_ati(None)
+            return
         self.plan.focus_dev(bufs[1], self.s2)
         if self.fused_mask:
             outs = dict(self.outs, ati_phase=self.masked)          # the phase plane comes out masked; no unmasked copy is kept

@@ -314,6 +314,15 @@ class CsaPlan:
         input of Context.ati_dpca_masked without a further pass over the image."""
         check(self.ctx.lib.sarx_csa_plan_set_max_slot(self.h, d_max.ptr if d_max is not None else None), self.ctx.h)
 
+    def set_ati(self, d_slc1, d_max=None, mask_frac=0.05, cal_phase=0.0, masked=None, slc1_mag=None, dpca_mag=None, keep_image=False):
+        """Every later focus_dev (the SECOND channel's) emits the ATI / DPCA products of (d_slc1, its own image) from its last
+        azimuth launch into the three fp32 device planes; d_slc1=None switches it off (sarx_csa_plan_set_ati)."""
+        if d_slc1 is None:
+            check(self.ctx.lib.sarx_csa_plan_set_ati(self.h, None, None, 0.0, 0.0, None, None, None, 0), self.ctx.h)
+            return
+        check(self.ctx.lib.sarx_csa_plan_set_ati(self.h, d_slc1.ptr, d_max.ptr, float(mask_frac), float(cal_phase), masked.ptr,
+                                                 slc1_mag.ptr, dpca_mag.ptr, int(bool(keep_image))), self.ctx.h)
+
     def focus_dev(self, d_phist, d_image):
         check(self.ctx.lib.sarx_csa_focus_dev(self.h, d_phist.ptr, d_image.ptr), self.ctx.h)
 

@@ -60,12 +60,15 @@ def test_config5_64_frames_two_channel_8192():
     mag = b.outs["slc1_mag"].download(np.float32, (8, n))
     # the driver masks inside the ATI launch (threshold from the focus's fused maximum) and keeps no unmasked phase: take it
     # from a plain ATI launch over the last frame's two images, which are still in the driver's buffers
-    assert b.fused_mask
+    assert b.fused_mask and b.fused_ati
     assert np.float32(mx) == b.d_max.download(np.float32, (256, 32))[:, 0].max()
+    # ... and emits the products from channel 2's last azimuth launch, so slc2 itself was never written: focus it here
+    b.plan.focus_dev(b.raw[-1][1], b.s2)
     plain = {k: ctx.alloc(n * n * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
     ctx.ati_dpca(b.s1, b.s2, n * n, 0.0, plain, want_stats=False)
     ph = plain["ati_phase"].download(np.float32, (8, n))
     np.testing.assert_array_equal(mag, plain["slc1_mag"].download(np.float32, (8, n)))
+    np.testing.assert_array_equal(b.outs["dpca_mag"].download(np.float32, (8, n)), plain["dpca_mag"].download(np.float32, (8, n)))
     for v in plain.values():
         v.release()
     thr = np.float32(mx) * np.float32(0.05)

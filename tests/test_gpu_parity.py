@@ -294,6 +294,49 @@ def test_fused_max_and_masked_ati(sx, ctx, n_az, n_rg):
     plan.close()
 
 
+@pytest.mark.parametrize("n_az,n_rg,keep", [(1024, 256, False), (2048, 512, True), (64, 128, False), (128, 64, True), (256, 1024, False),
+                                             (32, 32, True)])
+def test_ati_products_fused_into_second_focus(sx, ctx, n_az, n_rg, keep):
+    """sarx_csa_plan_set_ati: the second channel's last azimuth launch emits masked ATI phase, |slc1| and the DPCA magnitude -
+    bit for bit what the ATI launch computes from the two finished images (sar_ati_dcpa_sim_csa.py:414-419, 447-449) - with or
+    without writing slc2; the phase-balance sum agrees to rounding; sizes without the epilogue say so."""
+    from sarx import _ffi
+    raw, k = orc.point_scene(n_az, n_rg, seed=n_az + 11, clutter_db=-10.0)
+    args = orc.focus_args(k)
+    plan = _plan(sx, ctx, n_az, n_rg, args, flags=_ffi.FUSE_RANGE)
+    px = n_az * n_rg
+    d_in, d_in2 = ctx.to_device(raw), ctx.to_device(np.roll(raw, 1, axis=0) * np.complex64(0.9 + 0.1j))
+    s1, s2, s2f = ctx.alloc(px * 8), ctx.alloc(px * 8), ctx.alloc(px * 8)
+    d_max = ctx.alloc(_ffi.MAX_SLOT_BYTES)
+    plan.set_max_slot(d_max)
+    plan.focus_dev(d_in, s1)
+    plan.set_max_slot(None)
+    plan.focus_dev(d_in2, s2)
+    ref = {kk: ctx.alloc(px * 4) for kk in ("ati_phase", "slc1_mag", "dpca_mag")}
+    ctx.ati_dpca_masked(s1, s2, px, 0.3, d_max, 0.05, ref)
+    mx, sm = ctx.ati_stats()
+    got = {kk: ctx.alloc(px * 4) for kk in ("ati_phase", "slc1_mag", "dpca_mag")}
+    ctx.lib.sarx_memset(ctx.h, s2f.ptr, 0, px * 8)
+    plan.set_ati(s1, d_max, 0.05, 0.3, got["ati_phase"], got["slc1_mag"], got["dpca_mag"], keep_image=keep)
+    plan.focus_dev(d_in2, s2f)
+    plan.set_ati(None)
+    mx2, sm2 = ctx.ati_stats()
+    for kk in ref:
+        np.testing.assert_array_equal(got[kk].download(np.float32, (px,)), ref[kk].download(np.float32, (px,)))
+    assert 0 < np.count_nonzero(ref["ati_phase"].download(np.float32, (px,))) < px
+    assert mx2 == mx and abs(sm2 - sm) <= 1e-12 * abs(sm)
+    if keep:
+        np.testing.assert_array_equal(s2f.download(np.complex64, (px,)), s2.download(np.complex64, (px,)))
+    plan.focus_dev(d_in2, s2f)                                       # switched off again: an ordinary focus
+    np.testing.assert_array_equal(s2f.download(np.complex64, (px,)), s2.download(np.complex64, (px,)))
+    plan.close()
+    for shape, flags in (((256, 32), _ffi.FUSE_RANGE), ((64, 64), _ffi.FUSE_RANGE | _ffi.OUT_RG_MAJOR)):   # half-wave tiles; corner-turned output
+        other = _plan(sx, ctx, *shape, orc.focus_args(orc.scaled_radar(*shape)), flags=flags)
+        with pytest.raises(sx.SarxError):
+            other.set_ati(s1, d_max, 0.05, 0.0, got["ati_phase"], got["slc1_mag"], got["dpca_mag"])
+        other.close()
+
+
 def test_errors_are_loud(sx, ctx):
     k = orc.scaled_radar(64, 64)
     with pytest.raises(sx.SarxError):
