@@ -170,6 +170,12 @@ def run_batch_host(frame_ids_all, world, rank, process_frame, comm, slot_shape=N
 STACKS = ("multilook", "magnitude")
 
 
+class _Ptr:
+    """A bare device address where the engine wrappers expect a buffer object."""
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
 class TwoChannelBatch:
     """n_frames two-channel [n x n] complex64 scenes (the processing section of sar_ati_dcpa_sim_csa.py:402-449 per
     frame, frames independent as in sar_batch_sim.py:303-331), sharded frame f -> rank f mod world.
@@ -255,7 +261,10 @@ class TwoChannelBatch:
         if self.fused_mask:
             self.plan.set_max_slot(None)
         if self.fused_ati:
-            self.plan.set_ati(self.s1, self.d_max, self.mask_frac, 0.0, self.masked, self.outs["slc1_mag"], self.outs["dpca_mag"])
+            # the full-resolution magnitude slot IS the |slc1| plane of the products: written at its place in the stack buffer
+            self._slot_written = slot_ptr is not None and self.stack_kind == "magnitude"
+            mag = _Ptr(slot_ptr) if self._slot_written else self.outs["slc1_mag"]
+            self.plan.set_ati(self.s1, self.d_max, self.mask_frac, 0.0, self.masked, mag, self.outs["dpca_mag"])
             self.plan.focus_dev(bufs[1], self.s2)               # s2 serves as scratch only
             self.plan.set_ati(None)
             return
@@ -273,7 +282,7 @@ class TwoChannelBatch:
     def write_slot(self, dst_ptr):
         """The full-resolution magnitude slot (the multilook slot comes out of the focus itself)."""
         ctx = self.ctx
-        if self.stack_kind == "magnitude":
+        if self.stack_kind == "magnitude" and not getattr(self, "_slot_written", False):
             from ._ffi import check
             check(ctx.lib.sarx_magnitude_dev(ctx.h, self.s1.ptr, dst_ptr, self.px), ctx.h)
 
