@@ -148,8 +148,8 @@ int sarx_csa_plan_set_max_slot(sarx_plan* plan, float* d_max);
  * slc2 and reading both images again (keep_image != 0 also writes slc2 to d_image as usual; d_image is needed as scratch either
  * way).  d_max: the SARX_MAX_SLOT_BYTES slot of the plan that focused slc1.  sarx_ati_stats afterwards returns max|slc1| and the
  * phase-balance sum (fixed-order reduction: reproducible; not bit-identical to the separate launch's order of additions).
- * Power-of-two plans in the default image layout (n_rg a multiple of 64, or the last azimuth launch's tiles whole waves); takes
- * precedence over a look slot.
+ * Power-of-two plans (n_rg a multiple of 64, or the last azimuth launch's tiles whole waves) and the native 7199 x 13200, default
+ * image layout; takes precedence over a look slot.
  * d_slc1 = NULL switches it off. */
 int sarx_csa_plan_set_ati(sarx_plan* plan, const void* d_slc1, const float* d_max, float mask_frac, double cal_phase,
                           float* d_ati_phase_masked, float* d_slc1_mag, float* d_dpca_mag, int keep_image);

@@ -23,6 +23,7 @@
 #include "csa_kernels.h"
 #include "fft_mixed.hpp"
 #include "phase.hpp"
+#include "ati_pixel.hpp"
 
 namespace sarx {
 
@@ -128,6 +129,16 @@ __global__ __launch_bounds__(256) void pfa_dft23_kernel(PfaArgs a) {
     const unsigned k2 = blockIdx.y * 4 + (threadIdx.x >> 6);
     const bool live = (int)col < a.out_cols && k2 < (unsigned)P;
     float vmax = 0.f;
+    float ati_thr = 0.f;
+    double ati_re = 0.0, ati_im = 0.0;
+    if constexpr (EPI == 3) {                      // mask threshold: max over the shards the first channel's focus left
+        __shared__ float s_m[4];
+        float m = a.ati.thr[32 * threadIdx.x];     // 256 threads, MAX_SHARDS = 256
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+        __syncthreads();
+        ati_thr = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])) * a.ati.frac;
+    }
     if (live) {
         const unsigned colb = col * (unsigned)sizeof(cf);
         const char* __restrict__ src = reinterpret_cast<const char*>(a.u);
@@ -147,11 +158,25 @@ __global__ __launch_bounds__(256) void pfa_dft23_kernel(PfaArgs a) {
             else if constexpr (EPI == 2) {
                 x.x *= a.scale; x.y *= a.scale;
                 if (a.max_out) vmax = fmaxf(vmax, hypotf(x.x, x.y));      // max |image| for the ATI mask, as in az_tile_kernel
+            } else if constexpr (EPI == 3) {                               // the ATI / DPCA products instead of (or beside) the image
+                x.x *= a.scale; x.y *= a.scale;
+                const size_t o = (size_t)row * (a.pitch_out / (unsigned)sizeof(cf)) + col;
+                Pix px;
+                ati_pixel<false>(a.ati.s1[o], x, a.ati.cc, a.ati.cs, px);
+                a.ati.phase[o] = px.m1 > ati_thr ? px.phase : 0.f;
+                a.ati.m1[o] = px.m1;
+                a.ati.dm[o] = px.dm;
+                ati_re += px.sre; ati_im += px.sim;
             }
-            stnt(dst + oo, x, a.nt);
+            if (EPI != 3 || a.ati.keep_image) stnt(dst + oo, x, a.nt);
             row += a.c1k; oo += step;
             if (row >= (unsigned)N) { row -= N; oo -= wrap; }
         }
+    }
+    if constexpr (EPI == 3) {   // every lane arrives here (dead lanes carry 0): one partial per wave, finished in fixed order
+        for (int off = 32; off > 0; off >>= 1) { ati_re += __shfl_xor(ati_re, off, 64); ati_im += __shfl_xor(ati_im, off, 64); }
+        if ((threadIdx.x & 63) == 0)
+            a.ati.part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = make_double2(ati_re, ati_im);
     }
     if constexpr (EPI == 2) {
         if (a.max_out) {        // every lane arrives here (dead lanes carry 0): one sharded atomic per wave
@@ -163,6 +188,7 @@ __global__ __launch_bounds__(256) void pfa_dft23_kernel(PfaArgs a) {
 }
 
 bool az_pfa_supported(int n_az) { return n_az == pfa::N; }
+int az_pfa_ati_parts(int dst_cols) { return ((dst_cols + 63) / 64) * ((pfa::P + 3) / 4) * 4; }
 
 // ---- host tables ------------------------------------------------------------------------------------------------------
 static int pow_mod(long long b, long long e, long long m) {
@@ -241,7 +267,7 @@ AzPfa* az_pfa_create(size_t in_ld, size_t u_ld, size_t out_ld, hipError_t* err) 
 // dst: dense [7199 x dst_cols]; epi: 0 none, 1 Phi_1 (a.c1 / dt / t_start must be set), 2 scale
 hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, int src_cols, cf* u, size_t u_ld, cf* dst,
                       size_t dst_ld, int dst_cols, int epi, const double2* c1, double dt, double t_start, float scale,
-                      hipStream_t st, unsigned* max_out) {
+                      hipStream_t st, unsigned* max_out, const AtiFuse* ati) {
     using namespace pfa;
     constexpr int W = 32;
     PfaArgs a{};
@@ -251,6 +277,8 @@ hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, in
     a.offin = z->offin; a.offu = z->offu; a.bspec = inv ? z->bspec_i : z->bspec_f;
     a.c1 = c1; a.dt = dt; a.t_start = t_start; a.scale = scale; a.c1k = z->c1k; a.c2k = z->c2k;
     a.max_out = (inv && epi == 2) ? max_out : nullptr;
+    const bool fuse_ati = inv && epi == 2 && ati && ati->s1;
+    if (fuse_ati) a.ati = *ati;
     if (src_ld != z->in_ld || u_ld != z->u_ld || dst_ld != z->out_ld) return hipErrorInvalidValue;   // tables are per pitch
     a.off0in = (unsigned)(P * src_ld * sizeof(cf)); a.off0u = (unsigned)(P * u_ld * sizeof(cf));
     a.pitch_u = (unsigned)(u_ld * sizeof(cf)); a.pitch_out = (unsigned)(dst_ld * sizeof(cf));
@@ -268,7 +296,8 @@ hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, in
         if (epi == 1) hipLaunchKernelGGL((pfa_dft23_kernel<false, 1>), g2, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((pfa_dft23_kernel<false, 0>), g2, dim3(256), 0, st, a);
     } else {
-        if (epi == 2) hipLaunchKernelGGL((pfa_dft23_kernel<true, 2>), g2, dim3(256), 0, st, a);
+        if (fuse_ati) hipLaunchKernelGGL((pfa_dft23_kernel<true, 3>), g2, dim3(256), 0, st, a);
+        else if (epi == 2) hipLaunchKernelGGL((pfa_dft23_kernel<true, 2>), g2, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((pfa_dft23_kernel<true, 0>), g2, dim3(256), 0, st, a);
     }
     return hipGetLastError();

@@ -106,6 +106,15 @@ hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int 
 hipError_t launch_az_conv(int s, int ra, const AzArgs& a, hipStream_t st);
 
 // az_pfa.hip: prime-factor (23 x 313) azimuth transforms of the reference's native 7199 pulses, Rader for the 313
+// ATI / DPCA products emitted by a focus's last azimuth launch (sarx_csa_plan_set_ati): what that launch needs
+struct AtiFuse {
+    const float2* s1;                 // first channel's image [n_az x n_rg] (dense); NULL = off
+    float *phase, *m1, *dm;           // masked ATI phase, |slc1|, DPCA magnitude planes [n_az x n_rg]
+    double2* part;                    // one partial of sum slc1 conj(slc2) per wave of the launch
+    const float* thr;                 // MAX_SHARDS partial maxima of |slc1| (32 floats apart)
+    float cc, cs, frac;               // exp(i cal), mask fraction
+    int keep_image;
+};
 struct PfaArgs {
     const float2* in; size_t in_ld; int in_cols;      // dense source [7199 x in_cols]
     float2* u; size_t u_ld; int u_cols;                // intermediate, rows n1*313 + k2
@@ -119,6 +128,7 @@ struct PfaArgs {
     int c1k, c2k;                                      // output map k = (c1k k1 + c2k k2) mod 7199
     bool nt;                                           // nontemporal image loads / stores
     unsigned* max_out;                                 // inverse epilogue: [MAX_SHARDS x 32] partial maxima of |out| (AzArgs::max_out); NULL = off
+    AtiFuse ati;                                       // inverse epilogue 3: the products of (ati.s1, this image)
 };
 struct AzPfa;
 bool az_pfa_supported(int n_az);
@@ -128,7 +138,9 @@ void az_pfa_destroy(AzPfa* z);
 // epi: 0 none, 1 times Phi_1 (forward), 2 times scale (inverse).  src may equal dst; u is a [7199 x u_ld] work array
 hipError_t az_pfa_run(const AzPfa* z, bool inv, const float2* src, size_t src_ld, int src_cols, float2* u, size_t u_ld,
                       float2* dst, size_t dst_ld, int dst_cols, int epi, const double2* c1, double dt, double t_start,
-                      float scale, hipStream_t st, unsigned* max_out = nullptr);
+                      float scale, hipStream_t st, unsigned* max_out = nullptr, const AtiFuse* ati = nullptr);
+// partial sums the products epilogue of az_pfa_run writes for an image of dst_cols columns (one per wave)
+int az_pfa_ati_parts(int dst_cols);
 
 // products.hip
 struct AtiArgs {

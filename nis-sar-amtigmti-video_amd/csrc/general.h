@@ -17,6 +17,11 @@ void general_csa_destroy(GeneralCsa* g);
 hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, hipStream_t st);
 // max |image| slot ([MAX_SHARDS x 32] floats, AzArgs::max_out) filled by every later focus; false = this plan's route has no such epilogue
 bool general_csa_set_max_slot(GeneralCsa* g, unsigned* slot);
+// ATI / DPCA products out of the last inverse launch of every later focus (ati->part must hold the returned number of partials);
+// ati NULL or ati->s1 NULL = off (returns 0); -1 = this plan's route has no such epilogue
+struct AtiFuse;
+int general_csa_set_ati(GeneralCsa* g, const AtiFuse* ati);
+int general_csa_ati_parts(const GeneralCsa* g);
 uint64_t general_csa_bytes(const GeneralCsa* g);
 // one range pass (RangeMode) on a dense [n_az x n_rg] image; hipErrorNotSupported unless the range extent has a direct
 // mixed-radix line kernel (range_mixed.hip)

@@ -129,6 +129,7 @@ static hipError_t axis_init(Axis& ax, int n, int m_max, int direct_max, bool spl
 static void axis_free(Axis& ax) { hipFree(ax.chirp_f); hipFree(ax.chirp_i); hipFree(ax.bhat_f); hipFree(ax.bhat_i); }
 
 struct GeneralCsa {
+    AtiFuse ati{};                    // general_csa_set_ati: products out of the last inverse launch (prime-factor route)
     unsigned* max_slot = nullptr;     // general_csa_set_max_slot: partial maxima of |image| from the last inverse launch (prime-factor route)
     int n_az = 0, n_rg = 0, ldc = 0;
     sarx_radar_params p{};
@@ -444,7 +445,7 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
             const double dt = 1.0 / g->p.sample_rate_hz;
             GCK(az_pfa_run(g->pfa, false, d_in, n_rg, n_rg, wa, ld, g->data, n_rg, n_rg, 1, g->c1, dt, g->p.t_start_fast_s, 1.0f, st));
             GCK(general_csa_range_pass(g, RG_FUSED, g->data, g->data, st));
-            return az_pfa_run(g->pfa, true, g->data, n_rg, n_rg, wa, ld, d_out, n_rg, n_rg, 2, nullptr, 0.0, 0.0, 1.0f / (float)n_az, st, g->max_slot);
+            return az_pfa_run(g->pfa, true, g->data, n_rg, n_rg, wa, ld, d_out, n_rg, n_rg, 2, nullptr, 0.0, 0.0, 1.0f / (float)n_az, st, g->max_slot, &g->ati);
         }
         if (z3) {                     // azimuth FFT (:233) as a three-launch chirp-z with Phi_1 (:272-274) in its last epilogue
             const ColsSrc src{d_in, (size_t)n_rg, n_az, n_rg, az.chirp_f};
@@ -789,6 +790,14 @@ bool general_csa_set_max_slot(GeneralCsa* g, unsigned* slot) {
     if (slot && !(g->rg_mixed && g->pfa)) return false;      // only the 7199 x 13200 route has the reduction in its last launch
     g->max_slot = slot;
     return true;
+}
+
+int general_csa_ati_parts(const GeneralCsa* g) { return (g->rg_mixed && g->pfa) ? az_pfa_ati_parts(g->n_rg) : -1; }
+int general_csa_set_ati(GeneralCsa* g, const AtiFuse* ati) {
+    if (!ati || !ati->s1) { g->ati = AtiFuse{}; return 0; }
+    if (!(g->rg_mixed && g->pfa)) return -1;                   // only the 7199 x 13200 route has the epilogue
+    g->ati = *ati;
+    return az_pfa_ati_parts(g->n_rg);
 }
 
 void general_csa_destroy(GeneralCsa* g) {

@@ -498,9 +498,31 @@ int sarx_csa_plan_set_ati(sarx_plan* p, const void* d_slc1, const float* d_max, 
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
     sarx_ctx* c = p->ctx;
     hipSetDevice(c->device);
-    if (!d_slc1) { p->ati_s1 = nullptr; return SARX_OK; }
+    if (!d_slc1) {
+        p->ati_s1 = nullptr;
+        if (p->gen) general_csa_set_ati(p->gen, nullptr);
+        return SARX_OK;
+    }
     if (!d_max || !d_ati_phase_masked || !d_slc1_mag || !d_dpca_mag) return fail(c, SARX_ERR_INVALID, "NULL pointer");
-    if (p->gen || p->n_rg % 32 || (p->flags & SARX_OUT_RG_MAJOR) || p->slab_tiles > 0)
+    if (p->gen) {        // the native 7199 x 13200: the inverse DFT-23 launch of the prime-factor route has the same epilogue
+        const int parts = general_csa_ati_parts(p->gen);
+        if (parts < 0 || (p->flags & SARX_OUT_RG_MAJOR))
+            return fail(c, SARX_ERR_UNSUPPORTED, "the fused ATI products exist for power-of-two plans and 7199 x 13200 in the default image "
+                                                 "layout (sarx_ati_dpca_dev otherwise)");
+        if (!p->ati_part) {
+            hipError_t e = hipMalloc(&p->ati_part, ((size_t)parts + 128) * sizeof(double2));
+            if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc ATI partial sums: %s", hipGetErrorString(e));
+            p->bytes += (size_t)parts * sizeof(double2);
+        }
+        p->ati_nparts = parts;
+        AtiFuse f{};
+        f.s1 = (const float2*)d_slc1; f.phase = d_ati_phase_masked; f.m1 = d_slc1_mag; f.dm = d_dpca_mag; f.part = p->ati_part;
+        f.thr = d_max; f.cc = (float)cos(cal_phase); f.cs = (float)sin(cal_phase); f.frac = mask_frac; f.keep_image = keep_image != 0;
+        general_csa_set_ati(p->gen, &f);
+        p->ati_s1 = f.s1; p->ati_thr = d_max;
+        return SARX_OK;
+    }
+    if (p->n_rg % 32 || (p->flags & SARX_OUT_RG_MAJOR) || p->slab_tiles > 0)
         return fail(c, SARX_ERR_UNSUPPORTED, "the fused ATI products exist for power-of-two plans in the default image layout (sarx_ati_dpca_dev otherwise)");
     int w = (p->n_rg % 64 == 0) ? 64 : 32;          // 64 columns where n_rg allows: 256-byte row segments of the fp32 planes
     if (const char* ev = getenv("SARX_ATI_W")) { const int e = atoi(ev); if ((e == 32 || e == 64) && p->n_rg % e == 0) w = e; }
@@ -704,6 +726,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     if (p->gen) {
         float2* dst = rg_major ? p->buf_a : (float2*)d_image;
         HIPCHK(c, general_csa_focus(p->gen, (const float2*)d_phist, dst, c->stream));
+        if ((rc = ati_finish(p)) != SARX_OK) return rc;
         if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
         return SARX_OK;
     }

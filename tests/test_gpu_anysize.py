@@ -146,9 +146,32 @@ def test_native_scene_size_vs_oracle():
     ref = orc.sar_focus_csa_lean(raw, *args, workers=8, block=64)[0]
     assert orc.rel_l2(img.T, ref) < TOL
     assert orc.rel_l2(np.abs(img.T), np.abs(ref)) < TOL
+    # the product stage out of a second focus's last launch (sarx_csa_plan_set_ati) on the prime-factor route: bit for bit the
+    # separate launch's planes
+    d_in2, s2 = ctx.alloc(px * 8), ctx.alloc(px * 8)
+    ctx.fill_noise(d_in2, px, 7200)
+    plan.focus_dev(d_in2, s2)
+    ref_p = {kk: ctx.alloc(px * 4) for kk in ("ati_phase", "slc1_mag", "dpca_mag")}
+    ctx.ati_dpca_masked(d_out, s2, px, 0.2, d_max, 0.05, ref_p)
+    mx, sm = ctx.ati_stats()
+    got_p = {kk: ctx.alloc(px * 4) for kk in ("ati_phase", "slc1_mag", "dpca_mag")}
+    s2f = ctx.alloc(px * 8)
+    plan.set_ati(d_out, d_max, 0.05, 0.2, got_p["ati_phase"], got_p["slc1_mag"], got_p["dpca_mag"])
+    plan.focus_dev(d_in2, s2f)
+    plan.set_ati(None)
+    mx2, sm2 = ctx.ati_stats()
+    for kk in ref_p:
+        np.testing.assert_array_equal(got_p[kk].download(np.float32, (px,)), ref_p[kk].download(np.float32, (px,)))
+    assert mx2 == mx and abs(sm2 - sm) <= 1e-12 * abs(sm)
+    plan.focus_dev(d_in2, s2f)                                       # switched off: an ordinary focus again
+    np.testing.assert_array_equal(s2f.download(np.complex64, (px,)), s2.download(np.complex64, (px,)))
+    for b in (d_in2, s2, s2f, *ref_p.values(), *got_p.values()):
+        b.release()
     plan2 = sarx.CsaPlan(ctx, 100, 13200, *args)                     # chirp-z azimuth route: no such epilogue, and it says so
     with pytest.raises(sarx.SarxError):
         plan2.set_max_slot(d_max)
+    with pytest.raises(sarx.SarxError):
+        plan2.set_ati(d_out, d_max, 0.05, 0.0, d_max, d_max, d_max)
     plan2.close()
     for b in (d_in, d_out, d_max):
         b.release()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 3: two-channel n x n scene, CSA focus of both channels + ATI/DPCA on one MI355X.
-    python3 tools/bench_twochannel.py [size=8192] [frames=10]
+    python3 tools/bench_twochannel.py [size=8192 | native] [frames=10] [fused | masked | two-pass]
 Echoes are device-resident noise; prints ms per frame, frames/s, and the ATI/DPCA kernel's GB/s
 against its 28 B/pixel algorithmic traffic."""
 import os
@@ -11,11 +11,17 @@ sys.path.insert(0, os.path.join(ROOT, "nis-sar-amtigmti-video_amd"))
 import sarx  # noqa: E402
 from sarx import _ffi, radar  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+native = len(sys.argv) > 1 and sys.argv[1] == "native"            # the reference's own scene: 7199 pulses x 13200 samples per channel
+n = 8192 if native or len(sys.argv) < 2 else int(sys.argv[1])
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 ctx = sarx.Context(0)
-plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE)
-px = n * n
+if native:
+    n_az, n_rg = 7199, 13200
+    plan = sarx.CsaPlan(ctx, n_az, n_rg, *radar.focus_args())
+else:
+    n_az = n_rg = n
+    plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE)
+px = n_az * n_rg
 raw1, raw2, s1, s2 = (ctx.alloc(px * 8) for _ in range(4))
 outs = {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
 masked = ctx.alloc(px * 4)
@@ -69,7 +75,7 @@ ctx.record(1)
 ms = ctx.elapsed_ms(0, 1) / frames
 ati_ms /= frames
 how = {"fused": "products out of channel 2's last azimuth launch", "masked": "mask inside the ATI launch", "two-pass": "mask as a further launch"}[mode]
-print(f"two-channel {n}x{n}: {ms:.3f} ms/frame = {1e3 / ms:.1f} frames/s (2 x CSA focus + ATI/DPCA + mask; {how})")
+print(f"two-channel {n_az}x{n_rg}: {ms:.3f} ms/frame = {1e3 / ms:.1f} frames/s (2 x CSA focus + ATI/DPCA + mask; {how})")
 if mode == "fused":
     print(f"  channel 2's whole focus with the products in its last launch: {ati_ms:.3f} ms")
 else:

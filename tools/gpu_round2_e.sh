@@ -12,7 +12,7 @@ prof() {  # tag, program args...
 }
 echo "== plain runs"
 timeout -k 10 600 python bench.py --steps 20 --warmup 3 --stack both > gpurun_out/ev/bench.json 2> gpurun_out/ev/bench.err; echo "bench rc $?"
-for m in fused masked two-pass; do timeout -k 10 300 python tools/bench_twochannel.py 8192 10 $m >> gpurun_out/ev/twochannel.log 2>&1; echo "rc $?"; done; cat gpurun_out/ev/twochannel.log
+for m in fused masked two-pass; do timeout -k 10 300 python tools/bench_twochannel.py 8192 10 $m >> gpurun_out/ev/twochannel.log 2>&1; echo "rc $?"; timeout -k 10 300 python tools/bench_twochannel.py native 10 $m >> gpurun_out/ev/native_twochannel.log 2>&1; echo "rc $?"; done; cat gpurun_out/ev/twochannel.log gpurun_out/ev/native_twochannel.log
 timeout -k 10 300 python tools/bench_native.py > gpurun_out/ev/native.log 2>&1; echo "rc $?"; cat gpurun_out/ev/native.log
 timeout -k 10 300 python tools/bench_echo.py > gpurun_out/ev/echo.log 2>&1; echo "rc $?"; cat gpurun_out/ev/echo.log
 timeout -k 10 300 python tools/bench_videosar.py > gpurun_out/ev/videosar.log 2>&1; echo "rc $?"; cat gpurun_out/ev/videosar.log
