@@ -720,6 +720,8 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     sarx_ctx* c = p->ctx;
     hipSetDevice(c->device);
     if (!d_phist || !d_image || d_phist == d_image) return fail(c, SARX_ERR_INVALID, "image pointers NULL or aliased");
+    if (p->ati_s1 && (d_image == (const void*)p->ati_s1 || d_phist == (const void*)p->ati_s1))
+        return fail(c, SARX_ERR_INVALID, "the first channel's image (sarx_csa_plan_set_ati) must not be this focus's input or output: the output buffer is scratch");
     const bool rg_major = p->flags & SARX_OUT_RG_MAJOR;
     int rc;
     if (p->max_slot) HIPCHK(c, hipMemsetAsync(p->max_slot, 0, MAX_SLOT_BYTES, c->stream));

@@ -319,6 +319,8 @@ def test_ati_products_fused_into_second_focus(sx, ctx, n_az, n_rg, keep):
     ctx.lib.sarx_memset(ctx.h, s2f.ptr, 0, px * 8)
     plan.set_ati(s1, d_max, 0.05, 0.3, got["ati_phase"], got["slc1_mag"], got["dpca_mag"], keep_image=keep)
     plan.focus_dev(d_in2, s2f)
+    with pytest.raises(sx.SarxError):
+        plan.focus_dev(d_in2, s1)                                    # the first channel's image is not a valid scratch / output
     plan.set_ati(None)
     mx2, sm2 = ctx.ati_stats()
     for kk in ref:
