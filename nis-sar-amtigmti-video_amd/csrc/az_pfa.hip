@@ -147,8 +147,18 @@ __global__ __launch_bounds__(256) void pfa_dft23_kernel(PfaArgs a) {
         unsigned o = k2 * a.pitch_u + colb;                          // row n1*313 + k2: byte offset advances by 313 rows
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) { v[n1] = ldnt(src + o, a.nt); o += a.off0u; }
-        mix::dft_any<N1, INV>(v);
         unsigned row = (unsigned)(((unsigned long long)a.c2k * k2) % N);
+        cf s1v[EPI == 3 ? N1 : 1];                   // the first channel's samples, requested before the transform (az_tile_kernel does the same)
+        if constexpr (EPI == 3) {
+            unsigned rw = row;
+#pragma unroll
+            for (int k1 = 0; k1 < N1; ++k1) {
+                s1v[k1] = a.ati.s1[(size_t)rw * (a.pitch_out / (unsigned)sizeof(cf)) + col];
+                rw += a.c1k;
+                if (rw >= (unsigned)N) rw -= N;
+            }
+        }
+        mix::dft_any<N1, INV>(v);
         unsigned oo = row * a.pitch_out + colb;
         const unsigned step = (unsigned)a.c1k * a.pitch_out, wrap = (unsigned)N * a.pitch_out;
 #pragma unroll
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256) void pfa_dft23_kernel(PfaArgs a) {
                 x.x *= a.scale; x.y *= a.scale;
                 const size_t o = (size_t)row * (a.pitch_out / (unsigned)sizeof(cf)) + col;
                 Pix px;
-                ati_pixel<false>(a.ati.s1[o], x, a.ati.cc, a.ati.cs, px);
+                ati_pixel<false>(s1v[k1], x, a.ati.cc, a.ati.cs, px);
                 a.ati.phase[o] = px.m1 > ati_thr ? px.phase : 0.f;
                 a.ati.m1[o] = px.m1;
                 a.ati.dm[o] = px.dm;

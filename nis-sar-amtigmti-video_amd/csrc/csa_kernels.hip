@@ -258,6 +258,17 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
         for (int k = 1; k < AzCfg<R, W>::THREADS / 64; ++k) m = fmaxf(m, s_m[k]);
         ati_thr = m * a.ati_frac;
     }
+    // SCALE_ATI: the first channel's samples this thread will need, requested before the transform so that they arrive behind it
+    // (0.39 -> 0.35 ms for the launch at 8192^2: 135 VGPRs instead of 113, three waves per SIMD instead of four, and still faster)
+    cf s1v[EPI == AZ_EPI_SCALE_ATI ? P : 1];
+    if constexpr (EPI == AZ_EPI_SCALE_ATI) {
+        constexpr int RLp = E::R_last;
+#pragma unroll
+        for (int b = 0; b < P / RLp; ++b)
+#pragma unroll
+            for (int r = 0; r < RLp; ++r)
+                s1v[b * RLp + r] = a.ati_s1[(out_base + (size_t)E::out_index(t, b, r) * a.out_m_stride) * a.n_rg + col];
+    }
     stockham_run<R, W, INV, false>(v, t, c, lds, a.tw_r);
     constexpr int RL = E::R_last;
     float vmax = 0.f;
@@ -285,7 +296,7 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                 x.x *= a.scale; x.y *= a.scale;
                 const size_t o = rowo * a.n_rg + col;
                 Pix px;
-                ati_pixel<false>(a.ati_s1[o], x, a.ati_cc, a.ati_cs, px);
+                ati_pixel<false>(s1v[b * RL + r], x, a.ati_cc, a.ati_cs, px);
                 a.ati_phase[o] = px.m1 > ati_thr ? px.phase : 0.f;         // (:447-449)
                 a.ati_m1[o] = px.m1;
                 a.ati_dm[o] = px.dm;
