@@ -114,6 +114,9 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
     probe = b.stack(frames=[0, a.batch_frames - 1])
     assert np.isfinite(probe).all() and probe.min() >= 0 and probe.max() > 0, "stack slot not finite / empty"
     slot_bytes = b.slot_bytes
+    per_frame = ("focus(channel 1; its last launch also leaves max|slc1|" + (" and the multilooked stack slot" if stack == "multilook" else "") +
+                 ") + focus(channel 2; its last launch emits masked ATI phase, |slc1|, DPCA magnitude and never writes slc2)"
+                 if b.fused_ati else "focus x 2 + one ATI/DPCA launch" + (" with the mask inside" if b.fused_mask else " + one mask launch"))
     b.close()
     if rank != 0:
         return None
@@ -123,7 +126,7 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
                         f"frame f -> rank f mod {world}, every frame's two echo channels resident in HBM before the clock starts",
             "stack": (f"{LOOKS}x{LOOKS} multilook of |slc1|^2" if stack == "multilook" else "full-resolution |slc1|") +
                      f", {slot_bytes / 2**20:.0f} MiB per frame, gathered in place once per round of {world} frame(s)",
-            "gather_bytes_per_rank_per_round": slot_bytes}
+            "per_frame": per_frame, "gather_bytes_per_rank_per_round": slot_bytes}
 
 
 def main():
