@@ -139,7 +139,9 @@ int sarx_csa_plan_set_look_slot(sarx_plan* plan, int looks, float* d_slot);
  * hypotf the ATI launch computes) in d_max[SARX_MAX_SLOT_BYTES] as 256 partial maxima (float k*32, the rest zero; the maximum is
  * their maximum) - the last azimuth launch reduces them while it writes the image - so that
  * sarx_ati_dpca_masked_dev can apply the 5 % mask (sar_ati_dcpa_sim_csa.py:447-449) in the ATI pass itself instead of a further
- * pass over two planes.  Power-of-two plans and the native 7199 x 13200; d_max = NULL switches it off. */
+ * pass over two planes.  Power-of-two plans and the native 7199 x 13200; d_max = NULL switches it off.
+ * A focus that has sarx_csa_plan_set_ati armed neither clears nor reduces into the slot: it is the second channel's focus
+ * and READS the first channel's maximum from it, so one plan may keep both settings across the two focuses of a frame. */
 int sarx_csa_plan_set_max_slot(sarx_plan* plan, float* d_max);
 /* ATI / DPCA products fused into the focus of the SECOND channel: while d_slc1 is set, the last azimuth launch of every
  * sarx_csa_focus_dev of this plan reads slc1 = d_slc1 [n_az x n_rg] beside the samples of slc2 it is about to write and emits
@@ -149,7 +151,7 @@ int sarx_csa_plan_set_max_slot(sarx_plan* plan, float* d_max);
  * way).  d_max: the SARX_MAX_SLOT_BYTES slot of the plan that focused slc1.  sarx_ati_stats afterwards returns max|slc1| and the
  * phase-balance sum (fixed-order reduction: reproducible; not bit-identical to the separate launch's order of additions).
  * Power-of-two plans (n_rg a multiple of 64, or the last azimuth launch's tiles whole waves) and the native 7199 x 13200, default
- * image layout; takes precedence over a look slot.
+ * image layout; takes precedence over a look slot (while armed no look slot is written) and over the max slot (left as it is).
  * d_slc1 = NULL switches it off. */
 int sarx_csa_plan_set_ati(sarx_plan* plan, const void* d_slc1, const float* d_max, float mask_frac, double cal_phase,
                           float* d_ati_phase_masked, float* d_slc1_mag, float* d_dpca_mag, int keep_image);

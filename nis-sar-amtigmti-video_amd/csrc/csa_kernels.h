@@ -88,7 +88,7 @@ inline int persistent_grid(int wgs_per_cu, int cus, int work_items) {
 
 hipError_t launch_range_pass(int n_rg, int mode, const RangeArgs& a, hipStream_t st);
 // range_v2.hip: 32 points/thread, split re/im exchange (two lines resident per CU at 16384)
-bool range_v2_supported(int n_rg);
+bool range_v2_supported(int n_rg, int mode);
 hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st);
 // range_fused_wl.hip: fused FFT.Phi2.IFFT.Phi3 at 16384 with wave-private sub-transforms
 bool range_fused_wl_supported(int n_rg);

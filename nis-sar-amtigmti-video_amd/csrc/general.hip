@@ -445,7 +445,7 @@ hipError_t general_csa_focus(GeneralCsa* g, const float2* d_in, float2* d_out, h
             const double dt = 1.0 / g->p.sample_rate_hz;
             GCK(az_pfa_run(g->pfa, false, d_in, n_rg, n_rg, wa, ld, g->data, n_rg, n_rg, 1, g->c1, dt, g->p.t_start_fast_s, 1.0f, st));
             GCK(general_csa_range_pass(g, RG_FUSED, g->data, g->data, st));
-            return az_pfa_run(g->pfa, true, g->data, n_rg, n_rg, wa, ld, d_out, n_rg, n_rg, 2, nullptr, 0.0, 0.0, 1.0f / (float)n_az, st, g->max_slot, &g->ati);
+            return az_pfa_run(g->pfa, true, g->data, n_rg, n_rg, wa, ld, d_out, n_rg, n_rg, 2, nullptr, 0.0, 0.0, 1.0f / (float)n_az, st, g->ati.s1 ? nullptr : g->max_slot, &g->ati);
         }
         if (z3) {                     // azimuth FFT (:233) as a three-launch chirp-z with Phi_1 (:272-274) in its last epilogue
             const ColsSrc src{d_in, (size_t)n_rg, n_az, n_rg, az.chirp_f};

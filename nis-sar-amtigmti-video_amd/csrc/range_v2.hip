@@ -256,20 +256,18 @@ template <int N> static hipError_t launch_v2_mode(int mode, const RangeArgs& a, 
         case RG_IFFT: return launch_v2<N, RG_IFFT>(a, cus, st);
         case RG_FFT_PHI2: return launch_v2<N, RG_FFT_PHI2>(a, cus, st);
         case RG_IFFT_PHI3: return launch_v2<N, RG_IFFT_PHI3>(a, cus, st);
-        case RG_FUSED: return launch_v2<N, RG_FUSED>(a, cus, st);
     }
     return hipErrorInvalidValue;
 }
 
-bool range_v2_supported(int n_rg) { return n_rg == 4096 || n_rg == 8192 || n_rg == 16384; }
+// Only the instantiations that are a default somewhere and fit their register budget are built: one transform per launch
+// at 16384 samples.  (The fused mode and the 4096 / 8192 forms spilled 20-140 B/lane at the 128-VGPR cap and lost to the
+// 16-point kernel and to range_fused_wl.hip; they were reachable through SARX_RANGE_IMPL=2 only and are gone.)
+bool range_v2_supported(int n_rg, int mode) { return n_rg == 16384 && mode != RG_FUSED; }
 
 hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st) {
-    switch (n_rg) {
-        case 4096: return launch_v2_mode<4096>(mode, a, cus, st);
-        case 8192: return launch_v2_mode<8192>(mode, a, cus, st);
-        case 16384: return launch_v2_mode<16384>(mode, a, cus, st);
-    }
-    return hipErrorInvalidValue;
+    if (!range_v2_supported(n_rg, mode)) return hipErrorInvalidValue;
+    return launch_v2_mode<16384>(mode, a, cus, st);
 }
 
 }  // namespace sarx

@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -104,6 +106,7 @@ struct sarx_ctx {
     static constexpr size_t COPY_CHUNK = (size_t)32 << 20;
     char* pin[COPY_THREADS] = {};
     hipStream_t copy_stream[COPY_THREADS] = {};
+    std::mutex copy_mu;                // the pinned chunks and copy streams are per-ctx state: one staged copy at a time
     ncclComm_t comm = nullptr;
     int n_ranks = 0, rank = 0;
     int range_impl = 0;                // SARX_RANGE_IMPL: 0 auto, 1 = 16 pts/thread, 2 = 32 pts/thread split exchange, 3 = fused wave-private
@@ -167,14 +170,26 @@ static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t by
     }
     constexpr int T = sarx_ctx::COPY_THREADS;
     constexpr size_t CH = sarx_ctx::COPY_CHUNK;
-    for (int i = 0; i < T; ++i) {
+    std::lock_guard<std::mutex> lock(c->copy_mu);      // ctypes callers release the GIL: two host threads may arrive on one ctx
+    if (!c->pin[0] && (e = hipHostMalloc(&c->pin[0], CH, hipHostMallocDefault)) != hipSuccess) return e;
+    if (!c->copy_stream[0] && (e = hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking)) != hipSuccess) return e;
+    if (narrow && bytes <= CH) {      // a small complex128 upload: rounded on the calling thread through one chunk, no thread is started
+        const double* in = (const double*)src;
+        float* out = (float*)c->pin[0];
+        for (size_t k = 0; k < bytes / sizeof(float); ++k) out[k] = (float)in[k];
+        e = hipMemcpyAsync(dst, c->pin[0], bytes, hipMemcpyHostToDevice, c->copy_stream[0]);
+        return e != hipSuccess ? e : hipStreamSynchronize(c->copy_stream[0]);
+    }
+    for (int i = 1; i < T; ++i) {
         if (!c->pin[i] && (e = hipHostMalloc(&c->pin[i], CH, hipHostMallocDefault)) != hipSuccess) return e;
         if (!c->copy_stream[i] && (e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking)) != hipSuccess) return e;
     }
     hipError_t errs[T];
+    for (int i = 0; i < T; ++i) errs[i] = hipSuccess;
     std::vector<std::thread> th;
-    for (int i = 0; i < T; ++i)
-        th.emplace_back([=, &errs] {
+    // thread i copies chunks i, i + T, ...; if a thread cannot be started (std::system_error must not cross the C ABI) the
+    // calling thread does that share itself after the others
+    auto share = [=, &errs](int i) {
             hipError_t r = hipSetDevice(c->device);
             char* d = (char*)dst;
             const char* s0 = (const char*)src;
@@ -199,7 +214,13 @@ static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t by
             }
             if (r == hipSuccess) r = hipStreamSynchronize(c->copy_stream[i]);
             errs[i] = r;
-        });
+        };
+    std::vector<int> inline_shares;
+    for (int i = 0; i < T; ++i) {
+        try { th.emplace_back(share, i); }
+        catch (const std::system_error&) { inline_shares.push_back(i); }
+    }
+    for (int i : inline_shares) share(i);
     for (auto& t : th) t.join();
     for (int i = 0; i < T; ++i)
         if (errs[i] != hipSuccess) return errs[i];
@@ -583,7 +604,7 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
     const sarx_ctx* c = p->ctx;
     // measured on MI355X (profiles/): 32 pts/thread wins for one FFT per launch at n_rg >= 8192,
     // 16 pts/thread wins for the fused FFT+IFFT launch (the 32-pt form spills there)
-    const bool v2 = range_v2_supported(p->n_rg) &&
+    const bool v2 = range_v2_supported(p->n_rg, mode) &&
                     (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 16384 && mode != RG_FUSED));
     // impl 3 (default for the fused launch at 16384): wave-private sub-transforms
     if (mode == RG_FUSED && range_fused_wl_supported(p->n_rg) && (c->range_impl == 3 || c->range_impl == 0))
@@ -629,8 +650,8 @@ static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, v
         a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
         const bool look = inv && p->look_slot;
         if (look) { a.look_part = p->look_part; a.look = p->look; }
-        if (inv) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);
         const bool ati = inv && p->ati_s1;
+        if (inv && !ati) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);      // an armed ATI epilogue reads the slot (ati_thr): never reduce into it then
         if (ati) ati_args(p, a);
         HIPCHK(c, launch_az_tile(S, ati ? p->ati_w : p->az_w, inv, inv ? (ati ? AZ_EPI_SCALE_ATI : look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, nq, c->stream));
     }
@@ -638,7 +659,7 @@ static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, v
 }
 // the finish half of the fused multilook, after the last azimuth launch of a focus
 static int look_finish(sarx_plan* p) {
-    if (!p->look_slot) return SARX_OK;
+    if (!p->look_slot || p->ati_s1) return SARX_OK;      // the ATI epilogue takes precedence: no look partials were written
     sarx_ctx* c = p->ctx;
     HIPCHK(c, launch_look_finish(p->look_part, p->look_slot, p->n_az / p->look, p->n_rg / p->look, p->look, c->stream));
     return SARX_OK;
@@ -662,8 +683,8 @@ static int az_pass(sarx_plan* p, bool inv, const void* in, void* tmp, void* out)
         a.in_q_stride = 0; a.in_m_stride = 1; a.out_q_stride = 0; a.out_m_stride = 1;
         const bool look = inv && p->look_slot;
         if (look) { a.look_part = p->look_part; a.look = p->look; }
-        if (inv) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);
         const bool ati = inv && p->ati_s1;
+        if (inv && !ati) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);
         if (ati) ati_args(p, a);
         HIPCHK(c, launch_az_tile(n, ati ? p->ati_w : p->az_w, inv, inv ? (ati ? AZ_EPI_SCALE_ATI : look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, 1, c->stream));
         return SARX_OK;
@@ -678,6 +699,7 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
     sarx_ctx* c = p->ctx;
     hipSetDevice(c->device);
     if (!d_in || !d_out) return fail(c, SARX_ERR_INVALID, "NULL image pointer");
+    int rc;
     if (p->gen) {      // any-size plans: the range passes of a direct mixed-radix line length (13200) only
         int mode = -1;
         switch (pass_id) {
@@ -691,6 +713,8 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
         if (mode >= 0) e = general_csa_range_pass(p->gen, mode, (const float2*)d_in, (float2*)d_out, c->stream);
         else if (pass_id == SARX_PASS_AZ_FFT_PHI1 || pass_id == SARX_PASS_AZ_IFFT) {
             if (d_in == d_out) return fail(c, SARX_ERR_INVALID, "azimuth passes are out-of-place");
+            if (pass_id == SARX_PASS_AZ_IFFT && (p->max_slot || p->ati_s1))
+                return fail(c, SARX_ERR_UNSUPPORTED, "the per-pass azimuth IFFT of a 7199 x 13200 plan has no max-slot / ATI epilogue: switch them off or use sarx_csa_focus_dev");
             e = general_csa_az_pass(p->gen, pass_id == SARX_PASS_AZ_IFFT, (const float2*)d_in, (float2*)d_out, c->stream);
         }
         if (e == hipErrorNotSupported)
@@ -704,8 +728,13 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
         case SARX_PASS_AZ_IFFT:
             if (d_in == d_out || d_in == p->buf_b || d_out == p->buf_b)
                 return fail(c, SARX_ERR_INVALID, "azimuth passes are out-of-place");
-            if (p->max_slot && pass_id == SARX_PASS_AZ_IFFT) HIPCHK(c, hipMemsetAsync(p->max_slot, 0, MAX_SLOT_BYTES, c->stream));
-            return az_pass(p, pass_id == SARX_PASS_AZ_IFFT, d_in, p->buf_b, d_out);
+            if (p->max_slot && !p->ati_s1 && pass_id == SARX_PASS_AZ_IFFT) HIPCHK(c, hipMemsetAsync(p->max_slot, 0, MAX_SLOT_BYTES, c->stream));
+            if ((rc = az_pass(p, pass_id == SARX_PASS_AZ_IFFT, d_in, p->buf_b, d_out)) != SARX_OK) return rc;
+            if (pass_id == SARX_PASS_AZ_IFFT) {      // the armed epilogues of the last azimuth launch need their finish launches here too
+                if ((rc = look_finish(p)) != SARX_OK) return rc;
+                if ((rc = ati_finish(p)) != SARX_OK) return rc;
+            }
+            return SARX_OK;
         case SARX_PASS_RG_FFT_PHI2: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FFT_PHI2, a)); return SARX_OK; }
         case SARX_PASS_RG_IFFT_PHI3: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_IFFT_PHI3, a)); return SARX_OK; }
         case SARX_PASS_RG_FUSED_23: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FUSED, a)); return SARX_OK; }
@@ -724,7 +753,10 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
         return fail(c, SARX_ERR_INVALID, "the first channel's image (sarx_csa_plan_set_ati) must not be this focus's input or output: the output buffer is scratch");
     const bool rg_major = p->flags & SARX_OUT_RG_MAJOR;
     int rc;
-    if (p->max_slot) HIPCHK(c, hipMemsetAsync(p->max_slot, 0, MAX_SLOT_BYTES, c->stream));
+    // the slot is cleared and re-reduced by every focus EXCEPT one with the ATI epilogue armed: that focus is the second
+    // channel's and reads the first channel's maximum from it (normally the same buffer) - clearing it there made the
+    // threshold 0 and the mask pass every pixel
+    if (p->max_slot && !p->ati_s1) HIPCHK(c, hipMemsetAsync(p->max_slot, 0, MAX_SLOT_BYTES, c->stream));
     if (p->gen) {
         float2* dst = rg_major ? p->buf_a : (float2*)d_image;
         HIPCHK(c, general_csa_focus(p->gen, (const float2*)d_phist, dst, c->stream));

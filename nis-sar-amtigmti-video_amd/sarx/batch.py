@@ -328,6 +328,6 @@ class TwoChannelBatch:
         return out
 
     def close(self):
-        for b in (self.s1, self.s2, self.masked, self.d_stack, *self.outs.values(), *(x for pair in self.raw for x in pair)):
+        for b in (self.s1, self.s2, self.masked, self.d_stack, self.d_max, *self.outs.values(), *(x for pair in self.raw for x in pair)):
             b.release()
         self.plan.close()

@@ -146,11 +146,26 @@ def phase_balance(slc1, slc2, *, ctx=None):
 
 def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz,
                    prf_hz, platform_speed_mps, range_ref_m, t_start_fast, mask_frac=0.05, cal_phase=0.0, *,
-                   ctx=None, pulse_shift=True):
+                   ctx=None, pulse_shift=True, return_slc2=True, unmasked_phase=False, device_output=False):
     """The reference script's processing section in one call
     (sar_ati_dcpa_sim_csa.py:402-419,447-449): pulse shift, CSA focus of both
-    channels, ATI/DPCA products.  Images stay on the GPU between the steps; with DeviceArray inputs (echo
-    generators called with device=True) nothing is uploaded at all."""
+    channels, ATI/DPCA products, 5 % magnitude mask.  Nothing visits the host between the steps; with DeviceArray
+    inputs (echo generators called with device=True) nothing is uploaded at all.
+
+    The product stage runs the way bench.py's driver (sarx.batch.TwoChannelBatch) runs it: channel 1's focus leaves
+    max|slc1| on the device while it writes the image (sarx_csa_plan_set_max_slot), and channel 2's last azimuth launch
+    reads slc1 beside the slc2 samples it holds and writes the masked ATI phase, |slc1| and the DPCA magnitude
+    (sarx_csa_plan_set_ati) - no host round trip for the threshold, no ATI or mask launch, neither image read again.
+    Sizes without that epilogue (anything but a power of two or 7199 x 13200) run the separate ATI launch with the
+    device-side threshold instead; the planes are bit-identical either way.
+
+    Returns a dict with the reference's variable names: slc1, slc2 ([N_rg x N_az] views like sar_focus_csa's),
+    slc1_mag, dpca_mag, ati_phase_masked, range_axis, cross_range, max_mag, sum_interf.
+    return_slc2=False   : channel 2's image is never written (the reference saves it, :457-461, hence the default)
+    unmasked_phase=True : also "ati_phase", the unmasked np.angle(slc1*conj(slc2)) of :415 (one more launch)
+    device_output=True  : the images and planes stay on the GPU ([N_az x N_rg] row-major DeviceBuffers; release() them),
+                          max_mag / sum_interf are still fetched (24 bytes)
+    """
     ctx = ctx or default_context()
     on_device = isinstance(raw_rx1, DeviceArray) and isinstance(raw_rx2, DeviceArray)
     if on_device:                      # echoes synthesised on the GPU: the pulse shift is two views, nothing is uploaded
@@ -166,30 +181,64 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
             platform_speed_mps, range_ref_m, t_start_fast)
     plan = _get_plan(ctx, n_az, n_rg, args, _ffi.FUSE_RANGE)
     n = n_az * n_rg
-    d_s1, d_s2 = ctx.alloc(n * 8), ctx.alloc(n * 8)
-    if on_device:
-        d_raw = None
-        plan.focus_dev(r1, d_s1)
-        plan.focus_dev(r2, d_s2)
-    else:
-        d_raw = ctx.alloc(n * 8)
-        d_raw.upload(r1)
-        plan.focus_dev(d_raw, d_s1)
-        ctx.sync()
-        d_raw.upload(r2)
-        plan.focus_dev(d_raw, d_s2)
-    outs = {k: ctx.alloc(n * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
-    max_mag, sum_interf = ctx.ati_dpca(d_s1, d_s2, n, cal_phase, outs)
-    thr = np.float32(max_mag) * np.float32(mask_frac)
-    d_masked = ctx.alloc(n * 4)
-    ctx.mask_phase(outs["ati_phase"], outs["slc1_mag"], n, thr, d_masked)
-    ra, ca = plan.axes()
-    res = {"slc1": d_s1.download(np.complex64, (n_az, n_rg)).T, "slc2": d_s2.download(np.complex64, (n_az, n_rg)).T,
-           "range_axis": ra, "cross_range": ca, "max_mag": max_mag, "sum_interf": sum_interf}
-    for k, v in outs.items():
-        res[k] = v.download(np.float32, (n_az, n_rg)).T
-    res["ati_phase_masked"] = d_masked.download(np.float32, (n_az, n_rg)).T
-    for b in (d_raw, d_s1, d_s2, d_masked, *outs.values()):
-        if b is not None:
-            b.release()
-    return res
+    bufs = {"slc1": ctx.alloc(n * 8), "slc2": ctx.alloc(n * 8), "d_max": ctx.alloc(_ffi.MAX_SLOT_BYTES)}
+    for k in ("ati_phase_masked", "slc1_mag", "dpca_mag"):
+        bufs[k] = ctx.alloc(n * 4)
+    d_raw = None if on_device else ctx.alloc(n * 8)
+    keep = set()
+    try:
+        try:                                                # channel 1: image + max|image| out of the same launch
+            plan.set_max_slot(bufs["d_max"])
+            have_max = True
+        except _ffi.SarxError:
+            have_max = False
+        if on_device:
+            plan.focus_dev(r1, bufs["slc1"])
+        else:
+            d_raw.upload(r1)
+            plan.focus_dev(d_raw, bufs["slc1"])
+            ctx.sync()                                      # d_raw is about to be overwritten
+            d_raw.upload(r2)
+        src2 = r2 if on_device else d_raw
+        fused = False
+        if have_max and not unmasked_phase:
+            try:                                            # channel 2: the products come out of its last azimuth launch
+                plan.set_ati(bufs["slc1"], bufs["d_max"], mask_frac, cal_phase, bufs["ati_phase_masked"], bufs["slc1_mag"],
+                             bufs["dpca_mag"], keep_image=return_slc2)
+                fused = True
+            except _ffi.SarxError:
+                fused = False
+        try:
+            plan.focus_dev(src2, bufs["slc2"])
+        finally:
+            if fused:
+                plan.set_ati(None)
+            if have_max:
+                plan.set_max_slot(None)
+        if not fused:
+            if unmasked_phase or not have_max:              # ATI launch, then the mask with the threshold taken on the device
+                bufs["ati_phase"] = ctx.alloc(n * 4)
+                outs = {"ati_phase": bufs["ati_phase"], "slc1_mag": bufs["slc1_mag"], "dpca_mag": bufs["dpca_mag"]}
+                ctx.ati_dpca(bufs["slc1"], bufs["slc2"], n, cal_phase, outs, want_stats=False)
+                ctx.mask_phase_frac(bufs["ati_phase"], bufs["slc1_mag"], n, mask_frac, bufs["ati_phase_masked"])
+            else:                                           # mask inside the ATI launch, threshold from channel 1's focus
+                outs = {"ati_phase": bufs["ati_phase_masked"], "slc1_mag": bufs["slc1_mag"], "dpca_mag": bufs["dpca_mag"]}
+                ctx.ati_dpca_masked(bufs["slc1"], bufs["slc2"], n, cal_phase, bufs["d_max"], mask_frac, outs)
+        max_mag, sum_interf = ctx.ati_stats()               # the only host synchronisation of the chain
+        ra, ca = plan.axes()
+        res = {"range_axis": ra, "cross_range": ca, "max_mag": max_mag, "sum_interf": sum_interf, "fused_products": fused}
+        names = ["slc1"] + (["slc2"] if (return_slc2 or not fused) else []) + ["slc1_mag", "dpca_mag", "ati_phase_masked"] + \
+                (["ati_phase"] if "ati_phase" in bufs else [])
+        for k in names:
+            if device_output:
+                res[k] = bufs[k]
+                keep.add(k)
+            else:
+                res[k] = bufs[k].download(np.complex64 if k in ("slc1", "slc2") else np.float32, (n_az, n_rg)).T
+        return res
+    finally:
+        for k, b in bufs.items():
+            if k not in keep:
+                b.release()
+        if d_raw is not None:
+            d_raw.release()

@@ -76,18 +76,28 @@ def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
                            platform_speed_mps, range_grp_m, 0.0)
     plan = _plan(ctx, n_r, n_p, prm)
     if on_device:          # device in, device out: only what the caller wants is downloaded afterwards
-        d_mag = ctx.alloc(n_p * n_r * 4)
-        d_st = [ctx.alloc(n_p * n_r * 8) if intermediates else None for _ in range(3)]
-        check(lib.sarx_rda_focus_dev(plan.h, phist.ptr, d_mag.ptr, *[b.ptr if b is not None else None for b in d_st]), ctx.h)
-        if device_output:
-            r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
-            check(lib.sarx_rda_axes(plan.h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
-            return (d_mag, r_ax, c_ax, *d_st, fd)
-        mag = d_mag.download(np.float32, (n_p, n_r))
-        stages = [b.download(np.complex64, (n_p, n_r)) if b is not None else None for b in d_st]
-        for b in (d_mag, *d_st):
-            if b is not None:
-                b.release()
+        bufs = []
+        handed_over = False
+        try:
+            d_mag = ctx.alloc(n_p * n_r * 4)
+            bufs.append(d_mag)
+            d_st = []
+            for _ in range(3):
+                d_st.append(ctx.alloc(n_p * n_r * 8) if intermediates else None)
+                bufs.append(d_st[-1])
+            check(lib.sarx_rda_focus_dev(plan.h, phist.ptr, d_mag.ptr, *[b.ptr if b is not None else None for b in d_st]), ctx.h)
+            if device_output:
+                r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
+                check(lib.sarx_rda_axes(plan.h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
+                handed_over = True
+                return (d_mag, r_ax, c_ax, *d_st, fd)
+            mag = d_mag.download(np.float32, (n_p, n_r))
+            stages = [b.download(np.complex64, (n_p, n_r)) if b is not None else None for b in d_st]
+        finally:               # a failing focus or download must not keep up to four image-sized buffers
+            if not handed_over:
+                for b in bufs:
+                    if b is not None:
+                        b.release()
     else:
         if device_output:
             raise ValueError("device_output needs a device input (DeviceArray .T)")

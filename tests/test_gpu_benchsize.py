@@ -226,11 +226,15 @@ def test_8192_two_channel_point_targets_vs_oracle(sx, ctx):
     ref = orc.ati_dpca(o1, o2)
     m = ref["mask"]
     assert m.sum() > 20
-    d = np.angle(np.exp(1j * (res["ati_phase"][m].astype(np.float64) - ref["ati_phase"][m])))
-    assert np.linalg.norm(d) / max(np.linalg.norm(ref["ati_phase"][m]), 1e-30) < TOL
+    # the form bench.py times (products out of channel 2's last azimuth launch, AZ_EPI_SCALE_ATI) directly against the oracle
+    assert res["fused_products"]
+    inside = ref["slc1_mag"] > 0.05 * ref["max_mag"] * (1 + 1e-4)
+    d = np.angle(np.exp(1j * (res["ati_phase_masked"][inside].astype(np.float64) - ref["ati_phase"][inside])))
+    assert np.linalg.norm(d) / max(np.linalg.norm(ref["ati_phase"][inside]), 1e-30) < TOL
     assert orc.rel_l2(res["slc1_mag"], ref["slc1_mag"]) < TOL
     assert orc.rel_l2(res["dpca_mag"][m], ref["dpca_mag"][m]) < 1e-3          # difference of nearly equal images
     assert (res["ati_phase_masked"][~m & (res["slc1_mag"] < 0.049 * ref["max_mag"])] == 0).all()
+    assert abs(res["max_mag"] - ref["max_mag"]) < 1e-5 * ref["max_mag"]
     # physics: the radial mover shows an ATI phase the stationary grid does not
     assert np.abs(ref["ati_phase"][m]).max() > 0.2
 

@@ -101,5 +101,5 @@ def test_device_resident_two_channel_chain():
     for d in dev:
         d.release()
     assert a["slc1"].shape == (2048, 128) and np.abs(a["slc1"]).max() > 0
-    for key in ("slc1", "slc2", "ati_phase", "dpca_mag", "ati_phase_masked"):
+    for key in ("slc1", "slc2", "slc1_mag", "dpca_mag", "ati_phase_masked"):
         np.testing.assert_array_equal(a[key], b[key])

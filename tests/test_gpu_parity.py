@@ -186,18 +186,69 @@ def test_ati_cal_phase_and_views(sx):
 
 
 def test_two_channel_end_to_end(sx):
+    """focus_ati_dpca = the fused product stage (max slot + ATI epilogue of channel 2's last azimuth launch), against the
+    oracle; the unmasked-phase form (separate ATI launch) gives the same planes bit for bit."""
     (r1, r2), k = orc.point_scene(512, 512, seed=31, clutter_db=-25.0, two_channel=True)
     args = orc.focus_args(k)
     res = sx.focus_ati_dpca(r1, r2, *args, pulse_shift=False)
+    assert res["fused_products"] and "ati_phase" not in res
     o1 = orc.sar_focus_csa(r1, *args)[0]
     o2 = orc.sar_focus_csa(r2, *args)[0]
     ref = orc.ati_dpca(o1, o2)
+    inside = ref["slc1_mag"] > 0.05 * ref["max_mag"] * (1 + 1e-4)          # away from the threshold: no borderline pixel
+    outside = ref["slc1_mag"] < 0.05 * ref["max_mag"] * (1 - 1e-4)
     assert orc.rel_l2(np.abs(res["slc1"]), np.abs(o1)) < TOL
+    assert orc.rel_l2(np.abs(res["slc2"]), np.abs(o2)) < TOL
     assert orc.rel_l2(res["slc1_mag"], ref["slc1_mag"]) < TOL
-    assert _masked_phase_err(res["ati_phase"], ref["ati_phase"], ref["mask"]) < TOL
+    assert _masked_phase_err(res["ati_phase_masked"], ref["ati_phase"], inside) < TOL
+    assert (res["ati_phase_masked"][outside] == 0).all()
+    assert abs(res["max_mag"] - ref["max_mag"]) < 1e-5 * ref["max_mag"]
+    assert abs(res["sum_interf"] - np.sum(o1 * np.conj(o2))) < 1e-4 * abs(np.sum(o1 * np.conj(o2)))
     assert orc.rel_l2(res["dpca_mag"], ref["dpca_mag"]) < 5e-4      # difference of nearly equal images
     # physics: DPCA suppresses the stationary scene relative to channel 1
     assert np.median(res["dpca_mag"][ref["mask"]] / res["slc1_mag"][ref["mask"]]) < 0.5
+    two = sx.focus_ati_dpca(r1, r2, *args, pulse_shift=False, unmasked_phase=True)
+    assert not two["fused_products"]
+    assert _masked_phase_err(two["ati_phase"], ref["ati_phase"], ref["mask"]) < TOL
+    for key in ("slc1", "slc2", "slc1_mag", "dpca_mag", "ati_phase_masked"):
+        np.testing.assert_array_equal(two[key], res[key])
+    lean = sx.focus_ati_dpca(r1, r2, *args, pulse_shift=False, return_slc2=False)
+    assert "slc2" not in lean
+    for key in ("slc1", "slc1_mag", "dpca_mag", "ati_phase_masked"):
+        np.testing.assert_array_equal(lean[key], res[key])
+
+
+def test_max_slot_and_ati_left_armed_together(sx, ctx):
+    """A C caller may leave sarx_csa_plan_set_max_slot armed while the second channel's focus runs with
+    sarx_csa_plan_set_ati: that focus reads the slot as its threshold and must neither clear nor re-reduce it
+    (it used to clear it: threshold 0, every pixel passed the mask, sarx_ati_stats reported max 0)."""
+    from sarx import _ffi
+    (r1, r2), k = orc.point_scene(256, 512, seed=7, clutter_db=-20.0, two_channel=True)
+    args = orc.focus_args(k)
+    plan = _plan(sx, ctx, 256, 512, args, flags=_ffi.FUSE_RANGE)
+    n = r1.size
+    d1, d2 = ctx.to_device(r1), ctx.to_device(r2)
+    s1, s2, d_max = ctx.alloc(n * 8), ctx.alloc(n * 8), ctx.alloc(_ffi.MAX_SLOT_BYTES)
+    planes = [ctx.alloc(n * 4) for _ in range(6)]
+    plan.set_max_slot(d_max)
+    plan.focus_dev(d1, s1)
+    plan.set_ati(s1, d_max, 0.05, 0.0, *planes[:3])
+    plan.focus_dev(d2, s2)                                   # max slot still armed
+    mx_armed, sum_armed = ctx.ati_stats()
+    got = [b.download(np.float32, r1.shape) for b in planes[:3]]
+    plan.set_ati(None)
+    plan.focus_dev(d1, s1)                                   # the careful order: slot unset before the second focus
+    plan.set_max_slot(None)
+    plan.set_ati(s1, d_max, 0.05, 0.0, *planes[3:])
+    plan.focus_dev(d2, s2)
+    plan.set_ati(None)
+    mx, sm = ctx.ati_stats()
+    assert mx_armed == mx > 0 and sum_armed == sm
+    for a, b in zip(got, planes[3:]):
+        np.testing.assert_array_equal(a, b.download(np.float32, r1.shape))
+    assert (got[0] == 0).mean() > 0.5                        # the mask really masks
+    for b in (d1, d2, s1, s2, d_max, *planes):
+        b.release()
 
 
 # ---- streaming helpers ---------------------------------------------------------------------
