@@ -1,0 +1,314 @@
+// Range passes for n_rg = 16384 on sixteen waves per line, the range spectrum kept in a PERMUTED order between the
+// two passes (sar_ati_dcpa_sim_csa.py:278-382).
+//
+// The spectrum of a range line exists only between the forward transform (+ Phi_2, :278-326) and the inverse
+// (+ Phi_3, :331-382); nothing else ever reads it, so its storage order is free.  With the order
+//
+//        P[q * 1024 + k2] = X[q + 16 k2]          (q = bin mod 16, k2 = bin div 16)
+//
+// each direction needs ONE workgroup-wide exchange instead of two: the forward transform is decimation in frequency
+// over 16 x 1024 and stops where its wave-private 1024-point transforms end (wave q holds X[q + 16 k2], lanes along
+// k2: a 512-byte contiguous store per wave instruction), the inverse starts from exactly that arrangement and mirrors it.
+//
+//   forward (FFT + Phi_2):   load x[n1*1024 + t]  (thread t of 1024, n1 = 0..15: 8 B per lane, 512 B per wave instruction)
+//                            radix-16 over n1, twiddle W_N^(t q)                               -> y_q[t]
+//                            CROSS exchange (2 barriers): wave w takes line q = w, lane l holds y_w[l + 64 r]
+//                            wave-private 1024-point transform as 16 . 4 . 16:
+//                              radix-16 over r, twiddle W_1024^(l ka)
+//                              lane bits 4,5 <-> register bits 0,1 by v_permlane16_swap / v_permlane32_swap (no LDS),
+//                              radix-4 over them, twiddle W_64^(l_lo ke)
+//                              one exchange through the wave's own row of the LDS image (no barrier), radix-16
+//                                                                                              -> X[w + 16 (lane + 64 kf)]
+//                            Phi_2 at the natural-order bin, store P[w*1024 + lane + 64 kf]
+//   inverse (IFFT + Phi_3):  the mirror image: load P, inverse radix-16, private exchange, inverse radix-4, swaps back,
+//                            inverse radix-16, CROSS exchange back, conj twiddle, inverse radix-16 over q, Phi_3 / N,
+//                            store x[n1*1024 + t]
+//   fused:                   forward . Phi_2 . inverse . Phi_3 in one launch (the spectrum never leaves the registers)
+//
+// One persistent 1024-thread workgroup per CU (complex cross image [16][1088] = 136 KiB), four waves per SIMD at
+// <= 128 VGPRs.  The one-direction kernels keep the NEXT line's samples in flight in 32 further VGPRs while the
+// current line is transformed: with one workgroup per CU and barriers the waves run in lockstep, so without it the
+// CU's memory pipe idles during the arithmetic (tools/overlapbench.hip: sequential = sum, prefetch = max).
+#include <cstdlib>
+#include "csa_kernels.h"
+#include "fft_core.hpp"
+#include "phase.hpp"
+
+#ifndef WP_PREFETCH
+#define WP_PREFETCH 1        // one-direction kernels: next line's loads issued before the wave-private phase
+#endif
+#ifndef WP_HOIST
+#define WP_HOIST 5           // bit 0: cross twiddles W_N^(t q) kept in registers (30), bit 1: W_1024^(l ka) (30), bit 2: W_64^(l_lo ke) (6)
+#endif
+#ifndef WP_NT
+#define WP_NT 3              // bit 0: nontemporal line loads, bit 1: nontemporal line stores
+#endif
+
+namespace sarx {
+namespace wp {
+
+constexpr int N = 16384, M = 1024, THREADS = 1024;
+constexpr int ROW = 1088;                                         // complex elements per row of the cross image (1024 + room for the padded private image)
+constexpr size_t LDS_BYTES = (size_t)16 * ROW * sizeof(cf);       // 139264
+constexpr int PF = 65, PI = 66;                                   // row pitch of the private [16 x 64] exchange image, forward / inverse (bank-conflict free each way)
+
+__device__ __forceinline__ cf cmulc(cf a, cf b) {                 // a * conj(b)
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+// w[k] = w1^k, k = 1..15 (w[0] unused): depth-4 multiplication tree
+__device__ __forceinline__ void powers16(cf w1, cf* w) {
+    w[1] = w1;
+#pragma unroll
+    for (int k = 2; k < 16; ++k) w[k] = cmul(w[k / 2], w[k - k / 2]);
+}
+__device__ __forceinline__ cf cis_neg(int num, float inv_den) { return cis_frac(-(float)num * inv_den); }   // exp(-2 pi i num/den), exact fp32 argument
+
+// lane bit 4 <-> register bit 0, lane bit 5 <-> register bit 1 of a 16-register complex array (an involution):
+// before: lane l = l_lo + 16 l_hi holds element (l_hi, ka) in v[ka];  after: lane l_lo + 16 (ka & 3) holds it in v[l_hi + 4 (ka >> 2)]
+__device__ __forceinline__ void swap_lane45_reg01(cf* v) {
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) {          // pairs (ka even, ka odd): v_permlane16_swap exchanges odd rows of the first with even rows of the second
+        {
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[g].x), __float_as_uint(v[g + 1].x), false, false);
+            v[g].x = __uint_as_float(r[0]); v[g + 1].x = __uint_as_float(r[1]);
+        }
+        {
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[g].y), __float_as_uint(v[g + 1].y), false, false);
+            v[g].y = __uint_as_float(r[0]); v[g + 1].y = __uint_as_float(r[1]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (g & 2) continue;                   // pairs (g, g + 2): v_permlane32_swap exchanges the upper half of the first with the lower half of the second
+        {
+            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g].x), __float_as_uint(v[g + 2].x), false, false);
+            v[g].x = __uint_as_float(r[0]); v[g + 2].x = __uint_as_float(r[1]);
+        }
+        {
+            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g].y), __float_as_uint(v[g + 2].y), false, false);
+            v[g].y = __uint_as_float(r[0]); v[g + 2].y = __uint_as_float(r[1]);
+        }
+    }
+}
+
+struct Tw {                 // thread constants (hoisted out of the line loop when WP_HOIST says so)
+    cf cw[16];              // W_N^(t q)
+    cf t1[16];              // W_1024^(l ka)
+    cf t2[4];               // W_64^(l_lo ke)
+};
+template <int WHICH> __device__ __forceinline__ void make_tw(Tw& tw, int t) {
+    const int l = t & 63;
+    if constexpr (WHICH & 1) powers16(cis_neg(t, 1.0f / N), tw.cw);
+    if constexpr (WHICH & 2) powers16(cis_neg(l, 1.0f / M), tw.t1);
+    if constexpr (WHICH & 4) {
+        tw.t2[1] = cis_neg(l & 15, 1.0f / 64);
+        tw.t2[2] = cmul(tw.t2[1], tw.t2[1]);
+        tw.t2[3] = cmul(tw.t2[2], tw.t2[1]);
+    }
+}
+
+// wave-private forward 1024-point transform: in v[r] = y[l + 64 r], out v[kf] = Y[lane + 64 kf]
+__device__ __forceinline__ void fwd1024(cf* v, int l, cf* row, const Tw& tw) {
+    dft16<false>(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw.t1[k]);
+    swap_lane45_reg01(v);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dft4<false>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+#pragma unroll
+        for (int ke = 1; ke < 4; ++ke) v[4 * c + ke] = cmul(v[4 * c + ke], tw.t2[ke]);
+    }
+    // element (ka = (l >> 4) + 4 c, ke, l_lo) -> register l_lo of lane ka + 16 ke
+    cf* wr = row + (l & 15) * PF + (l >> 4);
+    exchange_sync<true>();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int ke = 0; ke < 4; ++ke) wr[4 * c + 16 * ke] = v[4 * c + ke];
+    exchange_sync<true>();
+    const cf* rd = row + l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = rd[r * PF];
+    dft16<false>(v);
+}
+// its mirror: in v[kf] = Y[lane + 64 kf], out v[r] = 1024 * y[l + 64 r]
+__device__ __forceinline__ void inv1024(cf* v, int l, cf* row, const Tw& tw) {
+    dft16<true>(v);
+    cf* wr = row + l;
+    exchange_sync<true>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[r * PI] = v[r];
+    exchange_sync<true>();
+    const cf* rd = row + (l & 15) * PI + (l >> 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int ke = 0; ke < 4; ++ke) v[4 * c + ke] = rd[4 * c + 16 * ke];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int ke = 1; ke < 4; ++ke) v[4 * c + ke] = cmulc(v[4 * c + ke], tw.t2[ke]);
+        dft4<true>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    }
+    swap_lane45_reg01(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmulc(v[k], tw.t1[k]);
+    dft16<true>(v);
+}
+
+// forward head: v[n1] = x[n1*1024 + t] -> wave w holds y_w[l + 64 r]
+__device__ __forceinline__ void fwd_head(cf* v, int t, cf* lds, const Tw& tw, bool lead_barrier) {
+    dft16<false>(v);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw.cw[q]);
+    if (lead_barrier) __syncthreads();          // every wave has finished with its row of the previous line
+#pragma unroll
+    for (int q = 0; q < 16; ++q) lds[q * ROW + t] = v[q];
+    __syncthreads();
+    const cf* rd = lds + (t >> 6) * ROW + (t & 63);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = rd[64 * r];
+}
+// inverse tail: wave w holds 1024 * y_w[l + 64 r] -> v[n1] = N * x[n1*1024 + t]
+__device__ __forceinline__ void inv_tail(cf* v, int t, cf* lds, const Tw& tw) {
+    cf* wr = lds + (t >> 6) * ROW + (t & 63);
+    exchange_sync<true>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[64 * r] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = lds[q * ROW + t];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], tw.cw[q]);
+    dft16<true>(v);
+}
+
+template <bool NT> __device__ __forceinline__ void load_line(cf* v, const cf* __restrict__ p) {      // 16 accesses 1024 samples apart
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ld8<NT>(p + i * M);
+}
+template <bool NT> __device__ __forceinline__ void load_perm(cf* v, const cf* __restrict__ p) {      // 16 accesses 64 samples apart
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ld8<NT>(p + i * 64);
+}
+
+// Phi_2 on the permuted spectrum: register kf of lane `lane` of wave w is bin k = w + 16 lane + 1024 kf (kf >= 8: k - N)
+__device__ __forceinline__ void apply_phi2(cf* v, int w, int lane, double2 c2, double df) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        FixPhase q = phi2_seed(w + 16 * lane - half * (N / 2), M, c2, df);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[8 * half + i] = cmul(v[8 * half + i], q.next());
+    }
+}
+
+}  // namespace wp
+
+// MODE: RG_FFT_PHI2 (natural in, permuted out), RG_IFFT_PHI3 (permuted in, natural out), RG_FUSED (natural in and out),
+//       RG_FFT / RG_IFFT: the same without the phase (tests)
+template <int MODE>
+__global__ __launch_bounds__(wp::THREADS, 4) void range_wp_kernel(RangeArgs a) {
+    using namespace wp;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    constexpr bool FWD = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED);
+    constexpr bool INV = (MODE == RG_IFFT || MODE == RG_IFFT_PHI3 || MODE == RG_FUSED);
+    constexpr bool PRE = WP_PREFETCH && MODE != RG_FUSED;
+    constexpr bool NTL = WP_NT & 1, NTS = (WP_NT & 2) != 0;
+
+    Tw tw;
+    make_tw<WP_HOIST & 7>(tw, (int)threadIdx.x);
+
+    cf nxt[16];
+    int line = blockIdx.x;
+    if constexpr (PRE) {
+        if (line < a.n_az) {
+            const cf* src = a.in + (size_t)range_row(a, line) * N;
+            if constexpr (FWD) load_line<NTL>(nxt, src + threadIdx.x);
+            else load_perm<NTL>(nxt, src + (threadIdx.x >> 6) * M + (threadIdx.x & 63));
+        }
+    }
+    for (; line < a.n_az; line += gridDim.x) {
+        const int row = range_row(a, line);
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));                   // keep addresses per-line (no hoisting out of the loop + spilling)
+        const int w = t >> 6, l = t & 63;
+        make_tw<(~WP_HOIST) & 7>(tw, t);              // whatever is not kept across lines
+        const cf* __restrict__ src = a.in + (size_t)row * N;
+        cf* __restrict__ dst = a.out + (size_t)row * N;
+        cf* myrow = lds + w * ROW;
+
+        cf v[16];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = nxt[i];
+        } else {
+            if constexpr (FWD) load_line<NTL>(v, src + t);
+            else load_perm<NTL>(v, src + w * M + l);
+        }
+        const int next_line = line + gridDim.x;
+        auto prefetch = [&]() {
+            if constexpr (PRE) {
+                if (next_line < a.n_az) {
+                    const cf* nsrc = a.in + (size_t)range_row(a, next_line) * N;
+                    if constexpr (FWD) load_line<NTL>(nxt, nsrc + t);
+                    else load_perm<NTL>(nxt, nsrc + w * M + l);
+                }
+            }
+        };
+
+        if constexpr (FWD) {
+            fwd_head(v, t, lds, tw, line != (int)blockIdx.x);
+            if constexpr (!INV) prefetch();
+            fwd1024(v, l, myrow, tw);
+            if constexpr (MODE != RG_FFT) apply_phi2(v, w, l, a.c2[row], a.df);
+            if constexpr (!INV) {
+#pragma unroll
+                for (int kf = 0; kf < 16; ++kf) st8<NTS>(dst + w * M + l + 64 * kf, v[kf]);
+            }
+        }
+        if constexpr (INV) {
+            if constexpr (!FWD) { if (line != (int)blockIdx.x) __syncthreads(); }    // the previous line's column reads of this wave's row are done
+            inv1024(v, l, myrow, tw);
+            inv_tail(v, t, lds, tw);
+            if constexpr (!FWD) prefetch();
+            const float sc = a.inv_n;
+            if constexpr (MODE == RG_IFFT) {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) st8<NTS>(dst + t + n1 * M, make_float2(v[n1].x * sc, v[n1].y * sc));
+            } else {
+                FixPhase q = phi3_seed(t, M, a.c3[row], a.dt, a.t_start, a.t0);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    cf p = q.next();
+                    p.x *= sc; p.y *= sc;
+                    st8<NTS>(dst + t + n1 * M, cmul(v[n1], p));
+                }
+            }
+        }
+    }
+}
+
+bool range_wp_supported(int n_rg) { return n_rg == wp::N; }
+
+template <int MODE> static hipError_t launch_wp(const RangeArgs& a, int cus, hipStream_t st) {
+    auto k = range_wp_kernel<MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wp::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int grid = persistent_grid(1, cus, a.n_az);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(wp::THREADS), wp::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_range_wp(int mode, const RangeArgs& a, int cus, hipStream_t st) {
+    switch (mode) {
+        case RG_FFT: return launch_wp<RG_FFT>(a, cus, st);
+        case RG_IFFT: return launch_wp<RG_IFFT>(a, cus, st);
+        case RG_FFT_PHI2: return launch_wp<RG_FFT_PHI2>(a, cus, st);
+        case RG_IFFT_PHI3: return launch_wp<RG_IFFT_PHI3>(a, cus, st);
+        case RG_FUSED: return launch_wp<RG_FUSED>(a, cus, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace sarx

@@ -167,7 +167,7 @@ def run_batch_host(frame_ids_all, world, rank, process_frame, comm, slot_shape=N
 # ----------------------------------------------------------------------------------------------------------------
 # BASELINE config 5 on the device: a VideoSAR batch of two-channel scenes, frame f -> rank f mod N
 # ----------------------------------------------------------------------------------------------------------------
-STACKS = ("multilook", "magnitude")
+STACKS = ("multilook", "magnitude", "products")
 
 
 class _Ptr:
@@ -185,7 +185,10 @@ class TwoChannelBatch:
     slot:  stack="multilook": looks x looks mean of |slc1|^2 (1 MiB per 8192^2 frame - the display stack the
     reference's batch script keeps, 512^2 per frame, sar_batch_sim.py:322), emitted by channel 1's last azimuth launch
     as row-wise partial sums and finished by a small launch (the image is not read again);  stack="magnitude": |slc1| at full
-    resolution (256 MiB per 8192^2 frame: the configuration that loads xGMI).
+    resolution (256 MiB per 8192^2 frame: the configuration that loads xGMI);  stack="products": the frame's three GMTI
+    planes [masked ATI phase, |slc1|, DPCA magnitude] (:414-419,447-449; 768 MiB per 8192^2 frame - SURVEY.md 8(e)'s
+    [frames x 3 x n x n] product stack), written by channel 2's last azimuth launch straight at their place in the
+    stack buffer, so the per-frame products leave the GPU they were computed on instead of being overwritten.
 
     The stack lives in one device buffer [rounds][world][slot]; a frame's slot is produced directly at its place
     and each round is gathered IN PLACE (send = recv + rank * slot), so there is no send buffer to recycle and no
@@ -219,8 +222,8 @@ class TwoChannelBatch:
         # neither image is read again; sizes without that epilogue keep the separate launch
         self.fused_ati = bool(fused_ati) and self.fused_mask and n % 64 == 0
         self.d_max = ctx.alloc(_ffi.MAX_SLOT_BYTES)
-        self.slot_shape = (n // looks, n // looks) if stack == "multilook" else (n, n)
-        self.slot_bytes = self.slot_shape[0] * self.slot_shape[1] * 4
+        self.slot_shape = (n // looks, n // looks) if stack == "multilook" else (n, n) if stack == "magnitude" else (3, n, n)
+        self.slot_bytes = int(np.prod(self.slot_shape)) * 4
         self.n_rounds = rounds(self.n_frames, self.world)
         self.mine = shard_frames(self.n_frames, self.world, self.rank)
         self.d_stack = ctx.alloc(self.slot_bytes * self.world * self.n_rounds)
@@ -262,19 +265,29 @@ class TwoChannelBatch:
             self.plan.set_max_slot(None)
         if self.fused_ati:
             # the full-resolution magnitude slot IS the |slc1| plane of the products: written at its place in the stack buffer
-            self._slot_written = slot_ptr is not None and self.stack_kind == "magnitude"
-            mag = _Ptr(slot_ptr) if self._slot_written else self.outs["slc1_mag"]
-            self.plan.set_ati(self.s1, self.d_max, self.mask_frac, 0.0, self.masked, mag, self.outs["dpca_mag"])
+            self._slot_written = slot_ptr is not None and self.stack_kind in ("magnitude", "products")
+            masked, mag, dm = self.masked, self.outs["slc1_mag"], self.outs["dpca_mag"]
+            if self._slot_written and self.stack_kind == "magnitude":
+                mag = _Ptr(slot_ptr)
+            elif self._slot_written:                       # the three planes of the frame, in place in the stack
+                masked, mag, dm = (_Ptr(slot_ptr + i * self.px * 4) for i in range(3))
+            self.plan.set_ati(self.s1, self.d_max, self.mask_frac, 0.0, masked, mag, dm)
             self.plan.focus_dev(bufs[1], self.s2)               # s2 serves as scratch only
             self.plan.set_ati(None)
             return
         self.plan.focus_dev(bufs[1], self.s2)
+        self._slot_written = False
+        outs, masked = self.outs, self.masked
+        if slot_ptr is not None and self.stack_kind == "products":     # separate launches, same destination
+            masked = _Ptr(slot_ptr)
+            outs = dict(self.outs, slc1_mag=_Ptr(slot_ptr + self.px * 4), dpca_mag=_Ptr(slot_ptr + 2 * self.px * 4))
+            self._slot_written = True
         if self.fused_mask:
-            outs = dict(self.outs, ati_phase=self.masked)          # the phase plane comes out masked; no unmasked copy is kept
+            outs = dict(outs, ati_phase=masked)                    # the phase plane comes out masked; no unmasked copy is kept
             ctx.ati_dpca_masked(self.s1, self.s2, self.px, 0.0, self.d_max, self.mask_frac, outs)
         else:
-            ctx.ati_dpca(self.s1, self.s2, self.px, 0.0, self.outs, want_stats=False)
-            ctx.mask_phase_frac(self.outs["ati_phase"], self.outs["slc1_mag"], self.px, self.mask_frac, self.masked)
+            ctx.ati_dpca(self.s1, self.s2, self.px, 0.0, outs, want_stats=False)
+            ctx.mask_phase_frac(outs["ati_phase"], outs["slc1_mag"], self.px, self.mask_frac, masked)
 
     def _slot_ptr(self, i, r):
         return self.d_stack.ptr + (i * self.world + r) * self.slot_bytes
@@ -317,10 +330,9 @@ class TwoChannelBatch:
 
     def stack(self, frames=None):
         """The assembled [n_frames, H, W] float32 stack (or the listed frames of it) on the host."""
-        h, w = self.slot_shape
         if frames is None:
-            return self.d_stack.download(np.float32, (self.n_rounds * self.world, h, w))[:self.n_frames]
-        out = np.empty((len(frames), h, w), dtype=np.float32)
+            return self.d_stack.download(np.float32, (self.n_rounds * self.world, *self.slot_shape))[:self.n_frames]
+        out = np.empty((len(frames), *self.slot_shape), dtype=np.float32)
         from ._ffi import check
         for k, f in enumerate(frames):
             check(self.ctx.lib.sarx_memcpy_d2h(self.ctx.h, out[k].ctypes.data, self.d_stack.ptr + f * self.slot_bytes,

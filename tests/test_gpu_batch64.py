@@ -106,6 +106,48 @@ def test_magnitude_stack_slot_is_full_resolution_channel_1():
     b2.close()
 
 
+def test_products_stack_holds_every_frames_three_planes():
+    """stack="products" (the [frames x 3 x n x n] product stack): slot f = [masked ATI phase, |slc1|,
+    DPCA magnitude] of frame f, written in place by channel 2's last azimuth launch; equal bit for bit to the planes of
+    an independently focused frame f through separate ATI / mask launches, and to the form without the fused epilogue."""
+    import sarx
+    from sarx import _ffi, radar
+    from sarx.batch import TwoChannelBatch
+    ctx = sarx.default_context()
+    n, frames = 2048, 4
+    b = TwoChannelBatch(ctx, n, frames, stack="products")
+    assert b.fused_ati and b.slot_shape == (3, n, n) and b.slot_bytes == 3 * n * n * 4
+    b.run()
+    ctx.sync()
+    st = b.stack()
+    assert st.shape == (frames, 3, n, n) and np.isfinite(st).all()
+    b.close()
+    px = n * n
+    plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE)
+    raw, s1, s2 = ctx.alloc(px * 8), ctx.alloc(px * 8), ctx.alloc(px * 8)
+    outs = {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
+    masked = ctx.alloc(px * 4)
+    for f in (0, 3):
+        ctx.fill_noise(raw, px, 1000 + 2 * f)
+        plan.focus_dev(raw, s1)
+        ctx.fill_noise(raw, px, 1000 + 2 * f + 1)
+        plan.focus_dev(raw, s2)
+        mx, _ = ctx.ati_dpca(s1, s2, px, 0.0, outs)
+        ctx.mask_phase(outs["ati_phase"], outs["slc1_mag"], px, np.float32(mx) * np.float32(0.05), masked)
+        np.testing.assert_array_equal(st[f, 0], masked.download(np.float32, (n, n)))
+        np.testing.assert_array_equal(st[f, 1], outs["slc1_mag"].download(np.float32, (n, n)))
+        np.testing.assert_array_equal(st[f, 2], outs["dpca_mag"].download(np.float32, (n, n)))
+        assert 0.005 < (st[f, 0] == 0).mean() < 0.3           # noise frames: a few per cent of the pixels lie under 5 % of the maximum
+    for x in (raw, s1, s2, masked, *outs.values()):
+        x.release()
+    plan.close()
+    b2 = TwoChannelBatch(ctx, n, frames, stack="products", fused_ati=False)      # separate ATI launch, same destination
+    b2.run()
+    ctx.sync()
+    np.testing.assert_array_equal(b2.stack(), st)
+    b2.close()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -137,3 +179,29 @@ def test_two_ranks_one_gpu_equal_single_rank(tmp_path, stack, n, frames):
     assert s0.shape[0] == 2 * rounds
     np.testing.assert_array_equal(s0[:frames], single)           # N-rank stack == 1-rank stack, bit for bit, frame order
     assert (s0[frames:] == 0).all()                              # the pad slot of the last round is zeros, not a stale slot
+
+
+@pytest.mark.parametrize("stack", ["multilook", "products"])
+def test_rccl_two_gpus_equal_single_rank(tmp_path, stack):
+    """The RCCL path itself (in-place ncclAllGather per round on the comm stream) with one rank per GPU: needs two
+    devices, skipped on the one-GPU test box (the driver's 8-GPU node is the first place it can run)."""
+    import sarx
+    from sarx.batch import TwoChannelBatch
+    if sarx.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    n, frames = 1024, 5
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SARX_TEST_RCCL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_batch64_worker.py"), str(tmp_path), str(n),
+           str(frames), stack]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    s0 = np.load(tmp_path / "stack64_rank0.npy")
+    np.testing.assert_array_equal(s0, np.load(tmp_path / "stack64_rank1.npy"))
+    ctx = sarx.default_context()
+    b = TwoChannelBatch(ctx, n, frames, stack=stack)
+    b.run()
+    ctx.sync()
+    np.testing.assert_array_equal(s0[:frames], b.stack())
+    assert (s0[frames:] == 0).all()
+    b.close()

@@ -246,7 +246,7 @@ def test_max_slot_and_ati_left_armed_together(sx, ctx):
     assert mx_armed == mx > 0 and sum_armed == sm
     for a, b in zip(got, planes[3:]):
         np.testing.assert_array_equal(a, b.download(np.float32, r1.shape))
-    assert (got[0] == 0).mean() > 0.5                        # the mask really masks
+    assert (got[0] == 0).any() and (got[0] != 0).any()       # the mask really masks
     for b in (d1, d2, s1, s2, d_max, *planes):
         b.release()
 
