@@ -33,6 +33,7 @@ for _p in (ROOT, os.path.join(ROOT, "nis-sar-amtigmti-video_amd")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+XGMI_LINK_GBS = 153.0          # one xGMI link, per direction (7 links per GPU, point to point)
 LOOKS = 16
 
 
@@ -48,9 +49,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-batch", action="store_true", help="skip the batch64 block (BASELINE config 5)")
     ap.add_argument("--batch-frames", type=int, default=64)
     ap.add_argument("--batch-size", type=int, default=8192)
-    ap.add_argument("--stack", choices=("multilook", "magnitude", "both"), default="multilook",
+    ap.add_argument("--stack", choices=("multilook", "magnitude", "products", "both", "all"), default="multilook",
                     help="batch64 stack slot: 16x16 multilook (1 MiB/frame at 8192^2; headline), full-resolution "
-                         "magnitude (256 MiB/frame: loads xGMI), or both one after the other")
+                         "magnitude (256 MiB/frame: loads xGMI), products (masked ATI phase, |slc1|, DPCA magnitude: 768 MiB/frame, "
+                         "SURVEY.md 8(e)'s product stack), both = multilook + magnitude, all = the three one after the other")
+    ap.add_argument("--batch-reps", type=int, default=3, help="timed repetitions of the batch64 block (the median is reported; keeps the GPU busy long enough to be sampled)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank reports (rank, local rank, world) and exits before touching the GPU")
     return ap.parse_args(argv)
@@ -100,33 +103,54 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
                         host_comm=None if (use_rccl or world == 1) else host_comm)
     b.prepare()                                                  # echoes of this rank's frames resident in HBM before the clock
     b.run()                                                      # warm-up batch
-    barrier()
-    t0 = time.perf_counter()
-    b.run()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    times = []
+    for _ in range(max(1, a.batch_reps)):
+        barrier()
+        t0 = time.perf_counter()
+        b.run()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+    dt = sorted(times)[len(times) // 2]                            # the median repetition
     import numpy as np
     probe = b.stack(frames=[0, a.batch_frames - 1])
-    assert np.isfinite(probe).all() and probe.min() >= 0 and probe.max() > 0, "stack slot not finite / empty"
+    assert np.isfinite(probe).all() and np.abs(probe).max() > 0, "stack slot not finite / empty"
     slot_bytes = b.slot_bytes
     per_frame = ("focus(channel 1; its last launch also leaves max|slc1|" + (" and the multilooked stack slot" if stack == "multilook" else "") +
                  ") + focus(channel 2; its last launch emits masked ATI phase, |slc1|, DPCA magnitude and never writes slc2)"
                  if b.fused_ati else "focus x 2 + one ATI/DPCA launch" + (" with the mask inside" if b.fused_mask else " + one mask launch"))
+    n_rounds = b.n_rounds
     b.close()
     if rank != 0:
         return None
-    return {"metric": "VideoSAR batch frames/sec (two-channel CSA focus + ATI/DPCA + mask, stack all-gather)",
-            "value": a.batch_frames / dt, "unit": "frames/s", "batch_s": dt, "scaling": "strong", "n_gpus": world,
-            "workload": f"{a.batch_frames} frames x two-channel {a.batch_size}x{a.batch_size} complex64 (BASELINE config 5), "
-                        f"frame f -> rank f mod {world}, every frame's two echo channels resident in HBM before the clock starts",
-            "stack": (f"{LOOKS}x{LOOKS} multilook of |slc1|^2" if stack == "multilook" else "full-resolution |slc1|") +
-                     f", {slot_bytes / 2**20:.0f} MiB per frame, gathered in place once per round of {world} frame(s)",
-            "per_frame": per_frame, "gather_bytes_per_rank_per_round": slot_bytes}
+    what = {"multilook": f"{LOOKS}x{LOOKS} multilook of |slc1|^2", "magnitude": "full-resolution |slc1|",
+            "products": "masked ATI phase + |slc1| + DPCA magnitude, full resolution (the frame's three GMTI planes, written in place "
+                        "by channel 2's last azimuth launch)"}[stack]
+    # which stacks can scale: one round = one frame per rank; its all-gather brings (world - 1) slots into every rank, each over its own
+    # point-to-point xGMI link, and overlaps the NEXT round's focusing - so a round costs max(compute, slot / link rate)
+    compute_round = dt / n_rounds if world == 1 else None
+    link_s = slot_bytes / (XGMI_LINK_GBS * 1e9)
+    blk = {"metric": "VideoSAR batch frames/sec (two-channel CSA focus + ATI/DPCA + mask, stack all-gather)",
+           "value": a.batch_frames / dt, "unit": "frames/s", "batch_s": dt, "batch_s_all": [round(x, 5) for x in times], "scaling": "strong", "n_gpus": world,
+           "workload": f"{a.batch_frames} frames x two-channel {a.batch_size}x{a.batch_size} complex64 (BASELINE config 5), "
+                       f"frame f -> rank f mod {world}, every frame's two echo channels resident in HBM before the clock starts",
+           "stack": what + f", {slot_bytes / 2**20:.0f} MiB per frame, gathered in place once per round of {world} frame(s)",
+           "per_frame": per_frame, "gather_bytes_per_rank_per_round": slot_bytes,
+           "gather_s_per_round_at_one_xgmi_link": link_s}
+    if compute_round is not None:
+        blk["compute_s_per_frame_one_gpu"] = compute_round
+        blk["link_bound_at_8_gpus"] = bool(link_s > compute_round)
+        blk["expected_8_gpu_speedup_bound"] = round(8.0 * min(1.0, compute_round / link_s), 2) if link_s > 0 else 8.0
+        blk["scaling_note"] = ("with N ranks a round of N frames costs max(per-frame compute, slot bytes / 153 GB/s per link) because the in-place "
+                               "gather of round i overlaps the focusing of round i+1: this stack is " +
+                               ("LINK-bound at 8 GPUs (the >= 6x target is not expected to hold for it)" if link_s > compute_round
+                                else "compute-bound at 8 GPUs (the gather hides behind the next round)"))
+    return blk
 
 
 def main():
@@ -266,14 +290,18 @@ def main():
         names = {_ffi.PASS_AZ_FFT_PHI1: ("az_fft_phi1", 2), _ffi.PASS_RG_FFT_PHI2: ("rg_fft_phi2", 1),
                  _ffi.PASS_RG_IFFT_PHI3: ("rg_ifft_phi3", 1), _ffi.PASS_RG_FUSED_23: ("rg_fused_fft_phi2_ifft_phi3", 1),
                  _ffi.PASS_AZ_IFFT: ("az_ifft", 2)}
+        if n == 16384:   # the pair the unfused focus runs: spectrum in permuted order between the two launches (range_wp.hip)
+            names[_ffi.PASS_RG_FFT_PHI2_PERM] = ("rg_fft_phi2_permuted_spectrum", 1)
+            names[_ffi.PASS_RG_IFFT_PHI3_PERM] = ("rg_ifft_phi3_permuted_spectrum", 1)
         for pid, (nm, launches_) in names.items():
             plan.run_pass(pid, d_in, tmp)
             ctx.sync()
+            reps = 10
             ctx.record(250)
-            for _ in range(5):
+            for _ in range(reps):
                 plan.run_pass(pid, d_in, tmp)
             ctx.record(251)
-            ms = ctx.elapsed_ms(250, 251) / 5
+            ms = ctx.elapsed_ms(250, 251) / reps
             per_pass[nm] = {"ms": round(ms, 4), "launches": launches_,
                             "GBps_per_launch": round(16.0 * n * n * launches_ / ms / 1e6, 1)}
             if a.passes:
@@ -316,17 +344,24 @@ def main():
         }
         if collective:
             line["collective"] = {"transport": collective, "ranks": world, "rccl": rccl}
+            # false = RCCL did not come up on every rank and the slots travelled through host memory (a rehearsal on fewer devices
+            # than ranks, or a broken node): such a line is NOT an xGMI scaling measurement
+            line["collective_ok"] = bool(use_rccl)
         if not a.unfused:
             # SURVEY.md 8(d) counts 16 B/sample per FFT(+phase) pass; this launch does two of them (FFT+Phi2, IFFT+Phi3)
             # on one HBM round trip.  `achieved` counts the bytes it really moves (16 B/sample), once.
             line["roofline"]["survey_passes_in_launch"] = 2
         if per_pass:
             # the standalone range FFT + Phi_2 launch BASELINE.json's 70 % target names, and the others
-            p2 = per_pass["rg_fft_phi2"]
+            perm = "rg_fft_phi2_permuted_spectrum" in per_pass
+            p2 = per_pass["rg_fft_phi2_permuted_spectrum" if perm else "rg_fft_phi2"]
             line["roofline_rg_fft_phi2_pass"] = {
-                "bound": "hbm", "achieved": p2["GBps_per_launch"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "range_wp_kernel<FFT+Phi2> (spectrum stored in the permuted order its inverse reads)" if perm
+                else "range pass FFT+Phi2", "achieved": p2["GBps_per_launch"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": p2["GBps_per_launch"] / HBM_PEAK_GBS, "launch_ms": p2["ms"],
-                "note": "same launch outside the timed region; the default path runs it fused with pass 3"}
+                "note": "the fused range-FFT + chirp-scaling-phase launch north_star's 70 % target names, as the unfused focus runs it, "
+                        "timed outside the timed region (10 launches, HIP events on the ctx stream); the default path runs it "
+                        "fused with pass 3 in one launch"}
             line["passes"] = per_pass
 
     # the config-4 buffers make room for config 5
@@ -337,12 +372,12 @@ def main():
         d_recv.release()
 
     if not a.no_batch:
-        stacks = ("multilook", "magnitude") if a.stack == "both" else (a.stack,)
+        stacks = {"both": ("multilook", "magnitude"), "all": ("multilook", "magnitude", "products")}.get(a.stack, (a.stack,))
         for st in stacks:
             blk = run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, st)
             if rank == 0:
                 blk["collective"] = collective or "none (one rank)"
-                line["batch64" if st == "multilook" else "batch64_magnitude"] = blk
+                line["batch64" if st == "multilook" else "batch64_" + st] = blk
 
     if rank == 0:
         if world == 1 and not a.no_cpu:

@@ -70,6 +70,12 @@ typedef struct {
 #define SARX_PASS_RG_IFFT_PHI3 3  /* :331-382 */
 #define SARX_PASS_AZ_IFFT 4       /* :385 */
 #define SARX_PASS_RG_FUSED_23 23  /* passes 2 and 3 in one launch */
+/* Passes 2 and 3 with the range spectrum in the PERMUTED order the unfused focus keeps it in between its two range
+ * launches (n_rg = 16384 only; SARX_ERR_UNSUPPORTED otherwise):  P[(k mod 16) * 1024 + k div 16] = X[k], k the natural
+ * (numpy.fft.fftfreq) bin index.  The spectrum exists only between these two launches (:278-382 never hands it out), so its
+ * storage order is free, and this one lets each launch run with a single workgroup-wide exchange (csrc/range_wp.hip). */
+#define SARX_PASS_RG_FFT_PHI2_PERM 12   /* natural-order line in, permuted spectrum out */
+#define SARX_PASS_RG_IFFT_PHI3_PERM 13  /* permuted spectrum in, natural-order line out */
 
 /* ---- context ------------------------------------------------------------- */
 int sarx_init(int device_id, sarx_ctx** out_ctx);

@@ -6,7 +6,8 @@
 
 namespace sarx {
 
-enum RangeMode { RG_FFT = 0, RG_IFFT = 1, RG_FFT_PHI2 = 2, RG_IFFT_PHI3 = 3, RG_FUSED = 4 };
+enum RangeMode { RG_FFT = 0, RG_IFFT = 1, RG_FFT_PHI2 = 2, RG_IFFT_PHI3 = 3, RG_FUSED = 4,
+                 RG_CONV = 5 };   // range_mixed.hip: zero-padded FFT . mulvec . IFFT / N, cropped (a circular convolution that holds a 'same' convolution)
 enum AzEpilogue { AZ_EPI_NONE = 0, AZ_EPI_TWIDDLE = 1, AZ_EPI_PHI1 = 2, AZ_EPI_SCALE = 3,
                   AZ_EPI_TWCOL = 4,      // * W_M^(col*m_out), M = 1/tw_scale (32768-point line split, forward)
                   AZ_EPI_PROCOL = 5,     // inputs * W_M^(col*m_in) first, outputs * scale (its inverse)
@@ -37,6 +38,10 @@ struct RangeArgs {
     // line -> image row.  row_inner == 0: the launch covers rows 0 .. n_az-1.  Otherwise line i of the n_az lines of this
     // launch is row  row0 + i % row_inner + (i / row_inner) * row_stride  (the rows of a group of azimuth tiles: slab mode)
     int row0, row_inner, row_stride;
+    // RG_CONV: the input line holds conv_valid samples (leading dimension conv_in_ld), the rest of the transform length is zero;
+    // of the result the samples [conv_crop0, conv_crop0 + conv_out) go to the output line (leading dimension conv_out_ld)
+    int conv_valid, conv_crop0, conv_out;
+    size_t conv_in_ld, conv_out_ld;
 };
 __host__ __device__ inline int range_row(const RangeArgs& a, int line) {
     return a.row_inner ? a.row0 + line % a.row_inner + (line / a.row_inner) * a.row_stride : line;
@@ -96,6 +101,8 @@ hipError_t launch_range_fused_wl(const RangeArgs& a, int cus, hipStream_t st);
 // range_mixed.hip: direct mixed-radix lines (13200 = 24 * 22 * 25, the reference's native range extent), all modes
 bool range_mixed_supported(int n_rg);
 hipError_t launch_range_mixed(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st);
+bool range_conv_supported(int m);
+hipError_t launch_range_conv(int m, const RangeArgs& a, int cus, hipStream_t st);
 // r: FFT length of the tile (2..128), w: tile width in range samples (16 or 32), nq: tiles along azimuth
 hipError_t launch_az_tile(int r, int w, bool inv, int epi, const AzArgs& a, int nq, hipStream_t st);
 
@@ -141,6 +148,14 @@ hipError_t az_pfa_run(const AzPfa* z, bool inv, const float2* src, size_t src_ld
                       float scale, hipStream_t st, unsigned* max_out = nullptr, const AtiFuse* ati = nullptr);
 // partial sums the products epilogue of az_pfa_run writes for an image of dst_cols columns (one per wave)
 int az_pfa_ati_parts(int dst_cols);
+
+// az_pfa7200.hip: prime-factor (32 x 225) pulse-axis transforms of the Range-Doppler focuser at 7200 pulses
+bool az_pfa7200_supported(int n);
+hipError_t az_pfa7200_run(bool inv, const float2* src, size_t src_ld, int cols, float2* u, size_t u_ld, float2* dst, float* dst_mag,
+                          size_t dst_ld, int shift_in, int shift_out, const float* pre, float scale, hipStream_t st);
+// range_wp.hip: sixteen-wave range passes at 16384 samples with the spectrum in permuted order between FFT+Phi2 and IFFT+Phi3
+bool range_wp_supported(int n_rg);
+hipError_t launch_range_wp(int mode, const RangeArgs& a, int cus, hipStream_t st);
 
 // products.hip
 struct AtiArgs {

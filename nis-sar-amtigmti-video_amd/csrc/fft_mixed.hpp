@@ -143,18 +143,33 @@ template <int R, bool INV> __device__ __forceinline__ void dft_composite(cf* v) 
 template <int R, bool INV> __device__ __forceinline__ void dft_any(cf* v) {
     if constexpr (R == 1) return;
     else if constexpr (R == 2 || R == 4 || R == 8 || R == 16) dft<R, INV>(v);
+    else if constexpr (R == 32) dft32<INV>(v);
     else if constexpr (is_prime(R)) dft_prime<R, INV>(v);
     else dft_composite<R, INV>(v);
 }
 
 // v[r] *= w^r, r = 1..R-1, by a multiplication tree of depth ceil(log2 R)
 template <int R> __device__ __forceinline__ void apply_powers(cf* v, cf w1) {
-    cf w[R];
-    w[1] = w1;
+    if constexpr (R <= 25) {
+        cf w[R];
+        w[1] = w1;
 #pragma unroll
-    for (int r = 2; r < R; ++r) w[r] = cmul(w[r / 2], w[r - r / 2]);
+        for (int r = 2; r < R; ++r) w[r] = cmul(w[r / 2], w[r - r / 2]);
 #pragma unroll
-    for (int r = 1; r < R; ++r) v[r] = cmul(v[r], w[r]);
+        for (int r = 1; r < R; ++r) v[r] = cmul(v[r], w[r]);
+    } else {
+        // long radices: the upper half of the tree is consumed as it is produced, so at most R/2 + 1 powers are alive
+        // beside the R data registers (the plain form keeps all R and spills under a 128-VGPR cap)
+        constexpr int H = (R + 1) / 2;
+        cf w[H + 1];
+        w[1] = w1;
+#pragma unroll
+        for (int r = 2; r <= H; ++r) w[r] = cmul(w[r / 2], w[r - r / 2]);
+#pragma unroll
+        for (int r = H + 1; r < R; ++r) v[r] = cmul(v[r], cmul(w[r / 2], w[r - r / 2]));
+#pragma unroll
+        for (int r = 1; r <= H; ++r) v[r] = cmul(v[r], w[r]);
+    }
 }
 
 }  // namespace mix

@@ -43,7 +43,7 @@ hipError_t scale_copy_cols(const float2* in, int in_rows, int in_cols, size_t in
 
 // Range-Doppler focuser (sar_satellite_sim.py:356-448); params.range_ref_m carries range_grp_m
 struct Rda;
-Rda* rda_create(int n_ranges, int n_pulses, const sarx_radar_params* prm, const float2* tw_all, std::string& err);
+Rda* rda_create(int n_ranges, int n_pulses, const sarx_radar_params* prm, const float2* tw_all, std::string& err, int cus = 0);
 void rda_destroy(Rda* r);
 // mag_out: device buffer for the [n_pulses x n_ranges] magnitude (nullptr: the object's own, see rda_mag);
 // want_rc: also keep the RCMC map (rda_stage(r, 2)); the other two intermediates are pipeline buffers and always valid

@@ -79,6 +79,26 @@ static void host_fft(std::vector<zd>& a) {           // iterative radix-2, forwa
     }
 }
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+// forward DFT of any length on the host, fp64: Bluestein's chirp-z over the radix-2 transform above
+static void host_dft_any(std::vector<zd>& a) {
+    const size_t n = a.size();
+    if (n && (n & (n - 1)) == 0) { host_fft(a); return; }
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    std::vector<zd> c(n), x(m, zd(0, 0)), b(m, zd(0, 0));
+    for (size_t k = 0; k < n; ++k) {
+        const unsigned long long k2 = ((unsigned long long)k * k) % (2ull * n);
+        c[k] = std::polar(1.0, -M_PI * (double)k2 / (double)n);
+        x[k] = a[k] * c[k];
+        b[k] = std::conj(c[k]);
+        if (k) b[m - k] = std::conj(c[k]);
+    }
+    host_fft(x);
+    host_fft(b);
+    for (size_t i = 0; i < m; ++i) x[i] = std::conj(x[i] * b[i]);      // inverse transform = conj(FFT(conj(.))) / m
+    host_fft(x);
+    for (size_t k = 0; k < n; ++k) a[k] = std::conj(x[k]) / (double)m * c[k];
+}
 
 struct Axis {
     int n = 0, m = 0;            // length, convolution length (m == n: direct power of two)
@@ -543,6 +563,8 @@ struct RdaArgsDev {
     int n_p, n_r;
     double k_rcmc;         // lambda^2 / (8 Vr^2)
     double k_ac;           // lambda / (2 Vr^2):  1/Ka = k_ac * r
+    const double2* rowc;   // [n_p] {s_k = 1 - alpha_k, 1 / s_k} (rda_rcmc_azcomp_rows_kernel: no fp64 division per pixel)
+    double inv_dr;         // (n_r - 1) / (r_axis[n_r - 1] - r_axis[0])
 };
 // out[k][j] = lerp of in[k][.] at u = (r_j/(1-a_k) - r_0)/dr, zero outside the sampled span
 __global__ __launch_bounds__(256) void rda_rcmc_kernel(RdaArgsDev a) {
@@ -623,6 +645,39 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_kernel(RdaArgsDev a, cf* 
         a.out[i] = cmul(y, cis_rev(g * fd2));
     }
 }
+// The same pass with one Doppler row per blockIdx.y and four range samples per thread: everything that depends on the row
+// only (s, 1/s, the span of the migrated axis) comes from a table built at plan creation, so a pixel costs one fused
+// multiply-add for its fractional position instead of three fp64 divisions (0.86 -> ms at 13200 x 7200: profiles/r03_f_*).
+// The bracketing sample is still checked against the actual positions r_axis[j] * s, as np.interp would find it.
+__global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a, cf* rc_out) {
+    const int k = blockIdx.y;
+    const double2 sc = a.rowc[k];
+    const double s = sc.x, r0 = a.r_axis[0];
+    const double x_first = r0 * s, x_last = a.r_axis[a.n_r - 1] * s;
+    const double c_a = sc.y * a.inv_dr, c_b = r0 * a.inv_dr;      // u = r_j / (s dr) - r_0 / dr;  1 / (x_b - x_a) = 1 / (s dr)
+    const double fd2 = a.fd[k] * a.fd[k];
+    const cf* row = a.in + (size_t)k * a.n_r;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j = blockIdx.x * 1024 + m * 256 + threadIdx.x;
+        if (j >= a.n_r) continue;
+        const double rj = a.r_axis[j];
+        cf y = make_float2(0.f, 0.f);
+        if (rj >= x_first && rj <= x_last) {
+            int j0 = (int)floor(fma(rj, c_a, -c_b));
+            if (j0 < 0) j0 = 0;
+            if (j0 > a.n_r - 2) j0 = a.n_r - 2;
+            while (j0 > 0 && a.r_axis[j0] * s > rj) --j0;
+            while (j0 < a.n_r - 2 && a.r_axis[j0 + 1] * s <= rj) ++j0;
+            const float f = (float)((rj - a.r_axis[j0] * s) * c_a);
+            const cf p = row[j0], q = row[j0 + 1];
+            y = make_float2(fmaf(f, q.x - p.x, p.x), fmaf(f, q.y - p.y, p.y));
+        }
+        const size_t i = (size_t)k * a.n_r + j;
+        if (rc_out) rc_out[i] = y;
+        a.out[i] = cmul(y, cis_rev(-0.5 * a.k_ac * rj * fd2));
+    }
+}
 __global__ __launch_bounds__(256) void rda_mag_kernel(const cf* in, float* mag, size_t n) {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) mag[i] = hypotf(in[i].x, in[i].y);
@@ -633,6 +688,12 @@ struct Rda {
     int n_p = 0, n_r = 0, m_c = 0, l_mf = 0;
     cf *hhat = nullptr, *win = nullptr;        // filter spectrum [m_c] (split order at 32768), azimuth window [n_p]
     cf* pre_f = nullptr;                       // chirp-z azimuth: pre-chirp[r] * window[(r + shift) mod n_p], per sequence index r
+    // direct route (13200 ranges x 7200 pulses, the satellite scripts' size): range compression as ONE circular convolution of
+    // length m_conv (range_mixed.hip, RG_CONV), pulse-axis transforms by the 32 x 225 prime-factor kernels (az_pfa7200.hip)
+    int m_conv = 0; cf* hhat_conv = nullptr;   // filter spectrum at m_conv points, natural order
+    bool pfa72 = false; float* winf = nullptr; // azimuth window as floats [n_p]
+    double2* rowc = nullptr; double inv_dr = 0;  // per Doppler row {1 - alpha, 1 / (1 - alpha)} for the row-wise RCMC kernel
+    int cus = 256;
     double *fd = nullptr, *r_axis = nullptr;
     cf *pc = nullptr, *rd = nullptr, *rc = nullptr;   // the three intermediates the reference returns
     float* mag = nullptr;
@@ -644,12 +705,12 @@ struct Rda {
 void rda_destroy(Rda* r) {
     if (!r) return;
     general_csa_destroy(r->g);
-    hipFree(r->hhat); hipFree(r->win); hipFree(r->pre_f); hipFree(r->fd); hipFree(r->r_axis);
+    hipFree(r->hhat); hipFree(r->win); hipFree(r->pre_f); hipFree(r->fd); hipFree(r->r_axis); hipFree(r->hhat_conv); hipFree(r->winf); hipFree(r->rowc);
     hipFree(r->pc); hipFree(r->rd); hipFree(r->rc); hipFree(r->mag);
     delete r;
 }
 
-Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw_all, std::string& err) {
+Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw_all, std::string& err, int cus) {
     // prm: wavelength, pulse width, chirp rate, sample rate, prf, platform speed, range_ref = range_grp_m
     const double fs = prm->sample_rate_hz, tp = prm->pulse_width_s, kr = prm->chirp_rate_hz_s;
     const int l_mf = (int)floor(tp / (1.0 / fs)) + 1;                 // :377-378
@@ -660,7 +721,17 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     Rda* r = new Rda();
     r->n_p = n_p; r->n_r = n_r; r->m_c = m_c; r->l_mf = l_mf;
     r->lam = prm->wavelength_m; r->vr = prm->platform_speed_mps; r->prf = prm->prf_hz;
-    r->g = general_csa_create(n_p, n_r, prm, tw_all, err, false);      // buffers and the azimuth axis only
+    if (cus > 0) r->cus = cus;
+    {   // direct route switches (SARX_RDA_DIRECT=0 keeps the chirp-z / padded power-of-two route for A/B)
+        const char* de = getenv("SARX_RDA_DIRECT");
+        const int direct = de ? atoi(de) : 1;
+        // a circular convolution of length M holds the 'same' window [c0, c0 + n_r) of the n_r + l_mf - 1 sample full
+        // convolution when the wrapped ends miss it: M >= full - c0 and M >= c0 + n_r
+        const int c0 = (l_mf - 1) / 2, full = n_r + l_mf - 1, m_need = std::max(full - c0, c0 + n_r);
+        if (direct && m_c > 16384 && range_conv_supported(19683) && m_need <= 19683 && n_r <= 19683) r->m_conv = 19683;
+        r->pfa72 = direct && az_pfa7200_supported(n_p);
+    }
+    r->g = general_csa_create(n_p, n_r, prm, tw_all, err, false, r->cus);      // buffers and the azimuth axis only
     if (!r->g) { delete r; return nullptr; }
     auto bail = [&](const char* what, hipError_t e) {
         err = std::string(what) + ": " + hipGetErrorString(e);
@@ -669,7 +740,7 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     };
     hipError_t e;
     // the convolution needs [n_p x m_c] work arrays
-    const size_t need = (size_t)n_p * m_c;
+    const size_t need = r->m_conv ? 0 : (size_t)n_p * m_c;
     if (need > r->g->work_elems) {
         hipFree(r->g->work_a); hipFree(r->g->work_b);
         r->g->work_a = r->g->work_b = nullptr;
@@ -688,13 +759,25 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     }
     nrm = sqrt(nrm);
     for (int k = 0; k < l_mf; ++k) h[k] /= nrm;
+    if (r->m_conv) {                 // the same taps at the circular length of the direct kernel
+        std::vector<zd> hc(r->m_conv, zd(0, 0));
+        for (int k = 0; k < l_mf; ++k) hc[k] = h[k];
+        host_dft_any(hc);
+        if ((e = upload(hc, &r->hhat_conv)) != hipSuccess) return bail("upload filter", e);
+    }
     host_fft(h);
     if (m_c > 16384) to_split_order(h);
     if ((e = upload(h, &r->hhat)) != hipSuccess) return bail("upload filter", e);
     std::vector<zd> win(n_p);
     for (int i = 0; i < n_p; ++i) win[i] = zd(n_p > 1 ? 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(n_p - 1)) : 1.0, 0.0);
     if ((e = upload(win, &r->win)) != hipSuccess) return bail("upload window", e);
-    if (!r->g->az.direct && cols_two_step(r->g->az.m)) {
+    if (r->pfa72) {
+        std::vector<float> wf(n_p);
+        for (int i = 0; i < n_p; ++i) wf[i] = (float)win[i].real();
+        if ((e = hipMalloc(&r->winf, n_p * sizeof(float))) != hipSuccess) return bail("hipMalloc window", e);
+        if ((e = hipMemcpy(r->winf, wf.data(), n_p * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload window", e);
+    }
+    if (!r->pfa72 && !r->g->az.direct && cols_two_step(r->g->az.m)) {
         // three-launch chirp-z along pulses: window and fftshift are folded into the copy-in; sequence element e is
         // source row (e + sh) mod n_p (the roll by n_p/2 of :396-399), so it carries chirp[e] * window[(e + sh) mod n_p]
         const int sh = (n_p - n_p / 2) % n_p;
@@ -720,6 +803,14 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     if ((e = hipMalloc(&r->r_axis, n_r * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemcpy(r->fd, r->h_fd.data(), n_p * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload", e);
     if ((e = hipMemcpy(r->r_axis, r->h_r.data(), n_r * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload", e);
+    {   // row constants of the RCMC pass (:414-418): alpha_k = fd_k^2 lambda^2 / (8 Vr^2)
+        const double k_rcmc = r->lam * r->lam / (8.0 * r->vr * r->vr);
+        std::vector<double2> rc(n_p);
+        for (int i = 0; i < n_p; ++i) { const double sk = 1.0 - r->h_fd[i] * r->h_fd[i] * k_rcmc; rc[i] = make_double2(sk, 1.0 / sk); }
+        if ((e = hipMalloc(&r->rowc, n_p * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMemcpy(r->rowc, rc.data(), n_p * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload", e);
+        r->inv_dr = (n_r > 1) ? (double)(n_r - 1) / (r->h_r[n_r - 1] - r->h_r[0]) : 1.0;
+    }
     const size_t img = (size_t)n_p * n_r;
     if ((e = hipMalloc(&r->pc, img * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&r->rd, img * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
@@ -736,16 +827,26 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out,
     const int n_p = r->n_p, n_r = r->n_r, m = r->m_c;
     cf* w = g->work_a;
     // 1 range compression
+    if (r->m_conv) {
+        // one launch: zero-padded FFT . filter spectrum . IFFT of every pulse at the circular length, 'same' window out (:388-392)
+        RangeArgs ca{};
+        ca.in = d_in; ca.out = r->pc; ca.n_az = n_p; ca.inv_n = 1.0f / (float)r->m_conv; ca.mulvec = r->hhat_conv; ca.mul_period = 1;
+        ca.conv_valid = n_r; ca.conv_crop0 = (r->l_mf - 1) / 2; ca.conv_out = n_r; ca.conv_in_ld = (size_t)n_r; ca.conv_out_ld = (size_t)n_r;
+        GCK(launch_range_conv(r->m_conv, ca, r->cus, st));
+    } else {
     // split lines (m > 16384): the zero padding is neither written nor read, and only the 'same' window is written back
     const int vin = m > 16384 ? n_r : 0, vout = m > 16384 ? (r->l_mf - 1) / 2 + n_r : 0;
     GCK(scale_copy(d_in, n_p, n_r, n_r, w, n_p, vin ? n_r : m, m, nullptr, nullptr, 1.0f, st));
     GCK(rows_pow2(g, w, n_p, m, false, st, r->hhat, 0, vin));    // * filter spectrum in the epilogue
     GCK(rows_pow2(g, w, n_p, m, true, st, nullptr, 0, vout));
     GCK(scale_copy(w + (r->l_mf - 1) / 2, n_p, n_r, m, r->pc, n_p, n_r, n_r, nullptr, nullptr, 1.0f, st));   // mode='same'
+    }
     // 2 window, fftshift . FFT . fftshift over pulses: roll by h = n_p/2 is source row (r - h) mod n
     const int h = n_p / 2, sh = (n_p - h) % n_p;
     const bool z3 = r->pre_f != nullptr;           // chirp-z along pulses in three launches, shifts / window / magnitude in its ends
-    if (z3) {
+    if (r->pfa72) {                                // two prime-factor launches, window and both fftshifts in their row addresses
+        GCK(az_pfa7200_run(false, r->pc, (size_t)n_r, n_r, g->work_a, (size_t)g->ldc, r->rd, nullptr, (size_t)n_r, sh, sh, r->winf, 1.0f, st));
+    } else if (z3) {
         const ColsSrc src{r->pc, (size_t)n_r, n_p, n_r, r->pre_f, sh};
         const ColsDst dst{r->rd, (size_t)n_r, n_p, n_r, g->az.chirp_f, 1.0f, (n_p - sh) % n_p, nullptr};
         GCK(cols_bluestein3(g, g->work_a, false, st, src, dst, AZ_EPI_CROPOUT));
@@ -757,11 +858,18 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out,
     a.fd = r->fd; a.r_axis = r->r_axis; a.n_p = n_p; a.n_r = n_r;
     a.k_rcmc = r->lam * r->lam / (8.0 * r->vr * r->vr);
     a.k_ac = r->lam / (2.0 * r->vr * r->vr);
-    dim3 grid((n_r + 255) / 256, n_p < 16384 ? n_p : 16384);
-    a.in = r->rd; a.out = g->data;
-    hipLaunchKernelGGL(rda_rcmc_azcomp_kernel, grid, dim3(256), 0, st, a, want_rc ? r->rc : (cf*)nullptr);
+    a.in = r->rd; a.out = g->data; a.rowc = r->rowc; a.inv_dr = r->inv_dr;
+    if (n_r > 1 && n_p <= 65535) {
+        hipLaunchKernelGGL(rda_rcmc_azcomp_rows_kernel, dim3((n_r + 1023) / 1024, n_p), dim3(256), 0, st, a, want_rc ? r->rc : (cf*)nullptr);
+    } else {
+        dim3 grid((n_r + 255) / 256, n_p < 16384 ? n_p : 16384);
+        hipLaunchKernelGGL(rda_rcmc_azcomp_kernel, grid, dim3(256), 0, st, a, want_rc ? r->rc : (cf*)nullptr);
+    }
     GCK(hipGetLastError());
     // 5 ifftshift . IFFT . ifftshift: source row (r + h) mod n both ways; magnitude
+    if (r->pfa72)
+        return az_pfa7200_run(true, g->data, (size_t)n_r, n_r, g->work_a, (size_t)g->ldc, nullptr, mag_out, (size_t)n_r, h, h, nullptr,
+                              1.0f / (float)n_p, st);
     if (z3) {
         const ColsSrc src{g->data, (size_t)n_r, n_p, n_r, g->az.chirp_i, h};
         const ColsDst dst{nullptr, (size_t)n_r, n_p, n_r, g->az.chirp_i, 1.0f / (float)n_p, (n_p - h) % n_p, mag_out};

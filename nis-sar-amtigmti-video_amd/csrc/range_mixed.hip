@@ -74,8 +74,8 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
     constexpr int N = C::N, R1 = C::R1, R2 = C::R2, R3 = C::R3, G1 = C::G1, G2 = C::G2, G3 = C::G3;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);
-    constexpr bool FWD = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED);
-    constexpr bool BWD = (MODE == RG_IFFT || MODE == RG_IFFT_PHI3 || MODE == RG_FUSED);
+    constexpr bool FWD = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED || MODE == RG_CONV);
+    constexpr bool BWD = (MODE == RG_IFFT || MODE == RG_IFFT_PHI3 || MODE == RG_FUSED || MODE == RG_CONV);
     // Phi_2 along a thread's bins k = t + r G3: non-negative frequencies for r <= R_LO and negative ones for r >= R_HI
     // whatever t is; in between (at most one r) it depends on the thread.  Each run is one fp64-seeded fixed-point phase
     // accumulator (phase.hpp), the in-between bins are evaluated directly.
@@ -85,15 +85,20 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
         const int row = range_row(a, line);
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));                     // per-line addresses: nothing hoisted out of the line loop and spilled
-        const cf* __restrict__ src = a.in + (size_t)row * N;
-        cf* __restrict__ dst = a.out + (size_t)row * N;
+        const cf* __restrict__ src = a.in + (size_t)row * (MODE == RG_CONV ? a.conv_in_ld : (size_t)N);
+        cf* __restrict__ dst = a.out + (size_t)row * (MODE == RG_CONV ? a.conv_out_ld : (size_t)N);
         cf v[C::RMAX];
         if (line != (int)blockIdx.x) __syncthreads();   // the previous line's last reads of the image are finished
         if constexpr (FWD) {
             // stage 1: radix R1, NS = 1, straight from HBM (8 bytes per lane, consecutive lanes consecutive samples)
             if (t < G1) {
+                if constexpr (MODE == RG_CONV) {         // the line is shorter than the transform: zeros beyond it, never read
 #pragma unroll
-                for (int r = 0; r < R1; ++r) v[r] = ld8<false>(src + t + r * G1);
+                    for (int r = 0; r < R1; ++r) v[r] = (t + r * G1 < a.conv_valid) ? ld8<false>(src + t + r * G1) : make_float2(0.f, 0.f);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R1; ++r) v[r] = ld8<false>(src + t + r * G1);
+                }
                 mix::dft_any<R1, false>(v);
                 cross1_write<R1, C::PITCH_F1>(v, t, lds);
             }
@@ -112,7 +117,11 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
                 cross2_read<R3, C::PITCH_F2>(v, t, lds);
                 mix_twiddle<R3, R1 * R2, false>(v, t);
                 mix::dft_any<R3, false>(v);
-                if constexpr (MODE == RG_FFT) {
+                if constexpr (MODE == RG_CONV) {      // times the filter spectrum, bins k = t + r G3 (the inverse starts from these registers)
+                    const cf* __restrict__ mv = a.mulvec;
+#pragma unroll
+                    for (int r = 0; r < R3; ++r) v[r] = cmul(v[r], mv[t + r * G3]);
+                } else if constexpr (MODE == RG_FFT) {
                     if (a.mulvec) {
                         const cf* __restrict__ mv = a.mulvec + (size_t)(row % a.mul_period) * N;
 #pragma unroll
@@ -165,7 +174,13 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
                 mix_twiddle<R1, R3 * R2, true>(v, t);
                 mix::dft_any<R1, true>(v);
                 const float s = a.inv_n;
-                if constexpr (MODE == RG_IFFT) {
+                if constexpr (MODE == RG_CONV) {      // only the cropped window is written
+#pragma unroll
+                    for (int r = 0; r < R1; ++r) {
+                        const int n = t + r * G1 - a.conv_crop0;
+                        if (n >= 0 && n < a.conv_out) st8<false>(dst + n, make_float2(v[r].x * s, v[r].y * s));
+                    }
+                } else if constexpr (MODE == RG_IFFT) {
 #pragma unroll
                     for (int r = 0; r < R1; ++r) dst[t + r * G1] = make_float2(v[r].x * s, v[r].y * s);
                 } else {
@@ -185,6 +200,13 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
 
 // ---- supported lengths ----------------------------------------------------------------------------------------------
 using Mix13200 = MixCfg<13200, 24, 22, 25, 640, 0, 8, 1, 3>;   // pads from the bank-conflict count of tools/lds_layout_sim.py
+// 19683 = 27^3: the circular length for the 'same' convolution of a 13200-sample line with the reference's 12001-tap
+// matched filter (sar_satellite_sim.py:377-392).  Any length >= 19200 holds it - the wrapped ends of the 25200-sample full
+// convolution then fall on the 6000 samples either side of the window that 'same' discards - and of the lengths whose
+// line fits LDS (<= 20480) 27^3 is the one whose three stages all have <= 768 butterflies (729): twelve waves, three per
+// SIMD, 168 VGPRs.  (19200 = 32 * 24 * 25 needs 800 butterflies in one stage: thirteen waves, four on one SIMD, 128 VGPRs,
+// and spilled 32 of them.)
+using Mix19683 = MixCfg<19683, 27, 27, 27, 768, 0, 2, 0, 2>;
 
 template <class C, int MODE> static hipError_t launch_mixed(const RangeArgs& a, int cus, hipStream_t st) {
     auto k = range_mixed_kernel<C, MODE>;
@@ -207,6 +229,16 @@ template <class C> static hipError_t launch_mixed_mode(int mode, const RangeArgs
 }
 
 bool range_mixed_supported(int n_rg) { return n_rg == 13200; }
+
+// circular convolution of every line with the filter whose m-point spectrum (natural bin order, NOT divided by m) is
+// a.mulvec: a.conv_* describe the zero padding and the crop.  m = 19683 only.
+bool range_conv_supported(int m) { return m == 19683; }
+hipError_t launch_range_conv(int m, const RangeArgs& a, int cus, hipStream_t st) {
+    if (m != 19683 || !a.mulvec || a.conv_valid <= 0 || a.conv_valid > m || a.conv_crop0 < 0 || a.conv_out <= 0 ||
+        a.conv_crop0 + a.conv_out > m)
+        return hipErrorInvalidValue;
+    return launch_mixed<Mix19683, RG_CONV>(a, cus, st);
+}
 
 hipError_t launch_range_mixed(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st) {
     switch (n_rg) {

@@ -35,7 +35,13 @@
 #include "phase.hpp"
 
 #ifndef WP_PREFETCH
-#define WP_PREFETCH 1        // one-direction kernels: next line's loads issued before the wave-private phase
+#define WP_PREFETCH 0        // one-direction kernels, next line's loads: 0 none, 1 one burst before the wave-private phase, 2 one burst at the
+#endif                       // top of the line, 3 four groups spread over the wave-private phase
+#ifndef WP_LAYOUT
+#define WP_LAYOUT 0          // spectrum order between the two passes: 0 = P[q*1024 + k2] (a wave's 8 KiB contiguous), 1 = P'[kf*1024 + q*64 + lane],
+#endif                       // k2 = lane + 64 kf (the sixteen waves of a workgroup fill each 8 KiB chunk together, like the natural-order side)
+#ifndef WP_ABL
+#define WP_ABL 0             // ablation builds (tools/rgbench.hip): 1 = no arithmetic (loads, exchanges, stores only), 2 = no exchanges either
 #endif
 #ifndef WP_HOIST
 #define WP_HOIST 5           // bit 0: cross twiddles W_N^(t q) kept in registers (30), bit 1: W_1024^(l ka) (30), bit 2: W_64^(l_lo ke) (6)
@@ -60,6 +66,16 @@ __device__ __forceinline__ void powers16(cf w1, cf* w) {
     w[1] = w1;
 #pragma unroll
     for (int k = 2; k < 16; ++k) w[k] = cmul(w[k / 2], w[k - k / 2]);
+}
+// One double2 of a per-row table through the SCALAR cache (p is wave-uniform).  vmcnt retires in order, so a vector load
+// of the row constants issued after the next line's prefetch would make the wave wait for the whole prefetch right there
+// (the compiler emits a vector load: it cannot prove the table is not written by the kernel).
+__device__ __forceinline__ double2 sload_double2(const double2* p) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    const unsigned long long lo = ((unsigned long long)r[1] << 32) | r[0], hi = ((unsigned long long)r[3] << 32) | r[2];
+    return make_double2(__longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
 }
 __device__ __forceinline__ cf cis_neg(int num, float inv_den) { return cis_frac(-(float)num * inv_den); }   // exp(-2 pi i num/den), exact fp32 argument
 
@@ -108,17 +124,30 @@ template <int WHICH> __device__ __forceinline__ void make_tw(Tw& tw, int t) {
 }
 
 // wave-private forward 1024-point transform: in v[r] = y[l + 64 r], out v[kf] = Y[lane + 64 kf]
-__device__ __forceinline__ void fwd1024(cf* v, int l, cf* row, const Tw& tw) {
+template <class HOOK>
+__device__ __forceinline__ void fwd1024(cf* v, int l, cf* row, const Tw& tw, HOOK hook) {
+    hook(0);
+#if WP_ABL == 0
     dft16<false>(v);
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw.t1[k]);
+#endif
+    hook(1);
+#if WP_ABL < 2
     swap_lane45_reg01(v);
+#endif
+#if WP_ABL == 0
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         dft4<false>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 #pragma unroll
         for (int ke = 1; ke < 4; ++ke) v[4 * c + ke] = cmul(v[4 * c + ke], tw.t2[ke]);
     }
+#endif
+    hook(2);
+#if WP_ABL == 2
+    return;
+#endif
     // element (ka = (l >> 4) + 4 c, ke, l_lo) -> register l_lo of lane ka + 16 ke
     cf* wr = row + (l & 15) * PF + (l >> 4);
     exchange_sync<true>();
@@ -130,11 +159,22 @@ __device__ __forceinline__ void fwd1024(cf* v, int l, cf* row, const Tw& tw) {
     const cf* rd = row + l;
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = rd[r * PF];
+    hook(3);
+#if WP_ABL == 0
     dft16<false>(v);
+#endif
 }
 // its mirror: in v[kf] = Y[lane + 64 kf], out v[r] = 1024 * y[l + 64 r]
-__device__ __forceinline__ void inv1024(cf* v, int l, cf* row, const Tw& tw) {
+template <class HOOK>
+__device__ __forceinline__ void inv1024(cf* v, int l, cf* row, const Tw& tw, HOOK hook) {
+    hook(0);
+#if WP_ABL == 0
     dft16<true>(v);
+#endif
+    hook(1);
+#if WP_ABL == 2
+    return;
+#endif
     cf* wr = row + l;
     exchange_sync<true>();
 #pragma unroll
@@ -145,23 +185,34 @@ __device__ __forceinline__ void inv1024(cf* v, int l, cf* row, const Tw& tw) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int ke = 0; ke < 4; ++ke) v[4 * c + ke] = rd[4 * c + 16 * ke];
+    hook(2);
+#if WP_ABL == 0
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int ke = 1; ke < 4; ++ke) v[4 * c + ke] = cmulc(v[4 * c + ke], tw.t2[ke]);
         dft4<true>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
     }
+#endif
     swap_lane45_reg01(v);
+    hook(3);
+#if WP_ABL == 0
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmulc(v[k], tw.t1[k]);
     dft16<true>(v);
+#endif
 }
 
 // forward head: v[n1] = x[n1*1024 + t] -> wave w holds y_w[l + 64 r]
 __device__ __forceinline__ void fwd_head(cf* v, int t, cf* lds, const Tw& tw, bool lead_barrier) {
+#if WP_ABL == 0
     dft16<false>(v);
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw.cw[q]);
+#endif
+#if WP_ABL == 2
+    return;
+#endif
     if (lead_barrier) __syncthreads();          // every wave has finished with its row of the previous line
 #pragma unroll
     for (int q = 0; q < 16; ++q) lds[q * ROW + t] = v[q];
@@ -172,6 +223,9 @@ __device__ __forceinline__ void fwd_head(cf* v, int t, cf* lds, const Tw& tw, bo
 }
 // inverse tail: wave w holds 1024 * y_w[l + 64 r] -> v[n1] = N * x[n1*1024 + t]
 __device__ __forceinline__ void inv_tail(cf* v, int t, cf* lds, const Tw& tw) {
+#if WP_ABL == 2
+    return;
+#endif
     cf* wr = lds + (t >> 6) * ROW + (t & 63);
     exchange_sync<true>();
 #pragma unroll
@@ -179,18 +233,18 @@ __device__ __forceinline__ void inv_tail(cf* v, int t, cf* lds, const Tw& tw) {
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = lds[q * ROW + t];
+#if WP_ABL == 0
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], tw.cw[q]);
     dft16<true>(v);
+#endif
 }
 
-template <bool NT> __device__ __forceinline__ void load_line(cf* v, const cf* __restrict__ p) {      // 16 accesses 1024 samples apart
+// registers [4 g0, 4 g1) of a line: 16 accesses STRIDE samples apart (1024: natural order, 64: permuted spectrum)
+template <bool NT, int STRIDE> __device__ __forceinline__ void load_regs(cf* v, const cf* __restrict__ p, int g0 = 0, int g1 = 4) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = ld8<NT>(p + i * M);
-}
-template <bool NT> __device__ __forceinline__ void load_perm(cf* v, const cf* __restrict__ p) {      // 16 accesses 64 samples apart
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = ld8<NT>(p + i * 64);
+    for (int i = 0; i < 16; ++i)
+        if (i >= 4 * g0 && i < 4 * g1) v[i] = ld8<NT>(p + i * STRIDE);
 }
 
 // Phi_2 on the permuted spectrum: register kf of lane `lane` of wave w is bin k = w + 16 lane + 1024 kf (kf >= 8: k - N)
@@ -214,20 +268,26 @@ __global__ __launch_bounds__(wp::THREADS, 4) void range_wp_kernel(RangeArgs a) {
     cf* lds = reinterpret_cast<cf*>(smem_raw);
     constexpr bool FWD = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED);
     constexpr bool INV = (MODE == RG_IFFT || MODE == RG_IFFT_PHI3 || MODE == RG_FUSED);
-    constexpr bool PRE = WP_PREFETCH && MODE != RG_FUSED;
+    constexpr bool PRE = WP_PREFETCH != 0 && MODE != RG_FUSED;
     constexpr bool NTL = WP_NT & 1, NTS = (WP_NT & 2) != 0;
 
     Tw tw;
     make_tw<WP_HOIST & 7>(tw, (int)threadIdx.x);
 
+    constexpr int STRIDE = (FWD || WP_LAYOUT == 1) ? M : 64;
+    const cf* nsrc = nullptr;                         // this thread's first sample of the line being prefetched
+    auto line_ptr = [&](int ln, int t) -> const cf* {
+        const cf* p = a.in + (size_t)range_row(a, ln) * N;
+        return (FWD || WP_LAYOUT == 1) ? p + t : p + (t >> 6) * M + (t & 63);
+    };
     cf nxt[16];
     int line = blockIdx.x;
     if constexpr (PRE) {
-        if (line < a.n_az) {
-            const cf* src = a.in + (size_t)range_row(a, line) * N;
-            if constexpr (FWD) load_line<NTL>(nxt, src + threadIdx.x);
-            else load_perm<NTL>(nxt, src + (threadIdx.x >> 6) * M + (threadIdx.x & 63));
-        }
+        if (line < a.n_az) load_regs<NTL, STRIDE>(nxt, line_ptr(line, threadIdx.x));
+        // land the first line here: the compiler merges the loop header's wait state over both predecessors, and with these
+        // loads still pending on entry it would wait vmcnt(0) at the top of EVERY line - i.e. for the previous line's stores,
+        // which are younger than that line's prefetch - instead of vmcnt(16)
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
     }
     for (; line < a.n_az; line += gridDim.x) {
         const int row = range_row(a, line);
@@ -235,7 +295,6 @@ __global__ __launch_bounds__(wp::THREADS, 4) void range_wp_kernel(RangeArgs a) {
         asm volatile("" : "+v"(t));                   // keep addresses per-line (no hoisting out of the loop + spilling)
         const int w = t >> 6, l = t & 63;
         make_tw<(~WP_HOIST) & 7>(tw, t);              // whatever is not kept across lines
-        const cf* __restrict__ src = a.in + (size_t)row * N;
         cf* __restrict__ dst = a.out + (size_t)row * N;
         cf* myrow = lds + w * ROW;
 
@@ -244,41 +303,52 @@ __global__ __launch_bounds__(wp::THREADS, 4) void range_wp_kernel(RangeArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = nxt[i];
         } else {
-            if constexpr (FWD) load_line<NTL>(v, src + t);
-            else load_perm<NTL>(v, src + w * M + l);
+            load_regs<NTL, STRIDE>(v, line_ptr(line, t));
         }
         const int next_line = line + gridDim.x;
-        auto prefetch = [&]() {
-            if constexpr (PRE) {
-                if (next_line < a.n_az) {
-                    const cf* nsrc = a.in + (size_t)range_row(a, next_line) * N;
-                    if constexpr (FWD) load_line<NTL>(nxt, nsrc + t);
-                    else load_perm<NTL>(nxt, nsrc + w * M + l);
-                }
-            }
+        const bool have_next = PRE && next_line < a.n_az;
+        if constexpr (PRE) { if (have_next) nsrc = line_ptr(next_line, t); }
+        // the next line's loads: where[] says after which point of the line they are issued
+        auto prefetch_all = [&]() { if (have_next) load_regs<NTL, STRIDE>(nxt, nsrc); };
+        auto group = [&](int gidx) { if (have_next) load_regs<NTL, STRIDE>(nxt, nsrc, gidx, gidx + 1); };
+        auto hook = [&](int point) {
+            if constexpr (WP_PREFETCH == 3) group(point);
+            if constexpr (WP_PREFETCH == 4) { if (point == 1) group(2); if (point == 3) group(3); }
+            if constexpr (WP_PREFETCH == 5) { if (point == 0) { group(0); group(1); } if (point == 2) { group(2); group(3); } }
         };
+        if constexpr (WP_PREFETCH == 2) prefetch_all();
+        if constexpr (WP_PREFETCH == 4) group(0);
 
         if constexpr (FWD) {
             fwd_head(v, t, lds, tw, line != (int)blockIdx.x);
-            if constexpr (!INV) prefetch();
-            fwd1024(v, l, myrow, tw);
-            if constexpr (MODE != RG_FFT) apply_phi2(v, w, l, a.c2[row], a.df);
+            if constexpr (!INV && WP_PREFETCH == 1) prefetch_all();
+            if constexpr (!INV && WP_PREFETCH == 4) group(1);
+            fwd1024(v, l, myrow, tw, hook);
+#if WP_ABL == 0
+            if constexpr (MODE != RG_FFT) apply_phi2(v, w, l, sload_double2(a.c2 + row), a.df);
+#endif
             if constexpr (!INV) {
 #pragma unroll
-                for (int kf = 0; kf < 16; ++kf) st8<NTS>(dst + w * M + l + 64 * kf, v[kf]);
+                for (int kf = 0; kf < 16; ++kf)
+#if WP_LAYOUT == 1
+                    st8<NTS>(dst + t + kf * M, v[kf]);
+#else
+                    st8<NTS>(dst + w * M + l + 64 * kf, v[kf]);
+#endif
             }
         }
         if constexpr (INV) {
-            if constexpr (!FWD) { if (line != (int)blockIdx.x) __syncthreads(); }    // the previous line's column reads of this wave's row are done
-            inv1024(v, l, myrow, tw);
+            if constexpr (!FWD) { if (WP_ABL < 2 && line != (int)blockIdx.x) __syncthreads(); }    // the previous line's column reads of this wave's row are done
+            inv1024(v, l, myrow, tw, hook);
             inv_tail(v, t, lds, tw);
-            if constexpr (!FWD) prefetch();
+            if constexpr (!FWD && WP_PREFETCH == 1) prefetch_all();
+            if constexpr (!FWD && WP_PREFETCH == 4) group(1);
             const float sc = a.inv_n;
-            if constexpr (MODE == RG_IFFT) {
+            if constexpr (MODE == RG_IFFT || WP_ABL != 0) {
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) st8<NTS>(dst + t + n1 * M, make_float2(v[n1].x * sc, v[n1].y * sc));
             } else {
-                FixPhase q = phi3_seed(t, M, a.c3[row], a.dt, a.t_start, a.t0);
+                FixPhase q = phi3_seed(t, M, sload_double2(a.c3 + row), a.dt, a.t_start, a.t0);
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) {
                     cf p = q.next();

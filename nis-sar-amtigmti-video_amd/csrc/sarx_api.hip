@@ -109,7 +109,7 @@ struct sarx_ctx {
     std::mutex copy_mu;                // the pinned chunks and copy streams are per-ctx state: one staged copy at a time
     ncclComm_t comm = nullptr;
     int n_ranks = 0, rank = 0;
-    int range_impl = 0;                // SARX_RANGE_IMPL: 0 auto, 1 = 16 pts/thread, 2 = 32 pts/thread split exchange, 3 = fused wave-private
+    int range_impl = 0;                // SARX_RANGE_IMPL: 0 auto, 1 = 16 pts/thread, 2 = 32 pts/thread split exchange, 3 = fused wave-private, 4 = sixteen-wave permuted-spectrum pair
     std::string err;
 };
 
@@ -738,6 +738,13 @@ int sarx_csa_pass(sarx_plan* p, int pass_id, const void* d_in, void* d_out) {
         case SARX_PASS_RG_FFT_PHI2: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FFT_PHI2, a)); return SARX_OK; }
         case SARX_PASS_RG_IFFT_PHI3: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_IFFT_PHI3, a)); return SARX_OK; }
         case SARX_PASS_RG_FUSED_23: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FUSED, a)); return SARX_OK; }
+        case SARX_PASS_RG_FFT_PHI2_PERM:
+        case SARX_PASS_RG_IFFT_PHI3_PERM: {
+            if (!range_wp_supported(p->n_rg)) return fail(c, SARX_ERR_UNSUPPORTED, "the permuted-spectrum range passes exist for n_rg = 16384 only");
+            RangeArgs a = range_args(p, d_in, d_out);
+            HIPCHK(c, launch_range_wp(pass_id == SARX_PASS_RG_FFT_PHI2_PERM ? RG_FFT_PHI2 : RG_IFFT_PHI3, a, c->cus, c->stream));
+            return SARX_OK;
+        }
         case 100: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_FFT, a)); return SARX_OK; }   // plain FFT (tests)
         case 101: { RangeArgs a = range_args(p, d_in, d_out); HIPCHK(c, run_range(p, RG_IFFT, a)); return SARX_OK; }  // plain IFFT (tests)
     }
@@ -797,6 +804,11 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     if (p->flags & SARX_FUSE_RANGE) {
         RangeArgs a = range_args(p, p->buf_b, p->buf_b);
         HIPCHK(c, run_range(p, RG_FUSED, a));
+    } else if (range_wp_supported(p->n_rg) && (c->range_impl == 0 || c->range_impl == 4)) {
+        // two launches with the spectrum in permuted order between them (range_wp.hip): one workgroup-wide exchange each
+        RangeArgs a = range_args(p, p->buf_b, p->buf_b);
+        HIPCHK(c, launch_range_wp(RG_FFT_PHI2, a, c->cus, c->stream));
+        HIPCHK(c, launch_range_wp(RG_IFFT_PHI3, a, c->cus, c->stream));
     } else {
         RangeArgs a = range_args(p, p->buf_b, p->buf_b);
         HIPCHK(c, run_range(p, RG_FFT_PHI2, a));
@@ -864,7 +876,7 @@ int sarx_rda_plan_create(sarx_ctx* c, int n_ranges, int n_pulses, const sarx_rad
         !(prm->pulse_width_s > 0))
         return fail(c, SARX_ERR_INVALID, "radar parameters must be positive");
     std::string err;
-    Rda* r = rda_create(n_ranges, n_pulses, prm, c->tw_all, err);
+    Rda* r = rda_create(n_ranges, n_pulses, prm, c->tw_all, err, c->cus);
     if (!r) return fail(c, SARX_ERR_UNSUPPORTED, "n_ranges=%d n_pulses=%d: %s", n_ranges, n_pulses, err.c_str());
     sarx_rda_plan* p = new sarx_rda_plan();
     p->ctx = c; p->r = r; p->n_r = n_ranges; p->n_p = n_pulses;

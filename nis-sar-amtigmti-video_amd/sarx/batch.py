@@ -199,7 +199,8 @@ class TwoChannelBatch:
     """
 
     def __init__(self, ctx, n, n_frames, world=1, rank=0, stack="multilook", looks=16, rccl=False, host_comm=None,
-                 seed_base=1000, flags=None, mask_frac=0.05, resident=True, fused_mask=True, fused_ati=True):
+                 seed_base=1000, flags=None, mask_frac=0.05, resident=True, fused_mask=True, fused_ati=True, scene="noise",
+                 scene_scale=1.0):
         from . import _ffi, radar
         from .engine import CsaPlan
         if stack not in STACKS:
@@ -211,7 +212,18 @@ class TwoChannelBatch:
         self.seed_base, self.mask_frac = int(seed_base), float(mask_frac)
         px = self.n * self.n
         self.px = px
-        self.plan = CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE if flags is None else flags)
+        # scene="noise": device-resident complex noise per (frame, channel) - bandwidth does not depend on content.
+        # scene="c3": SURVEY.md 8(d) C5's content - frame f is the C3 scene (5 x 5 grid + a 15 m/s radial mover + a slow mover,
+        # sarx.radar.c3_scene) with the movers advanced by f * 0.1 s, both receive channels synthesised on the device by the
+        # bistatic echo kernel over n + 1 pulses, the DPCA pulse shift (sar_ati_dcpa_sim_csa.py:402-403) as two views.
+        if scene not in ("noise", "c3"):
+            raise ValueError("scene must be 'noise' or 'c3'")
+        self.scene, self.scene_scale = scene, float(scene_scale)
+        self.k = radar.scaled_constants(n, n) if scene == "c3" else None
+        args = radar.focus_args(n) if scene == "noise" else (self.k["Lambda"], self.k["T_p"], self.k["Kr"], self.k["FS"], self.k["PRF"],
+                                                             self.k["V_eff"], self.k["R0"], self.k["t_start_fast"])
+        self.focus_args = args
+        self.plan = CsaPlan(ctx, n, n, *args, flags=_ffi.FUSE_RANGE if flags is None else flags)
         self.s1, self.s2 = ctx.alloc(px * 8), ctx.alloc(px * 8)
         self.outs = {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
         self.masked = ctx.alloc(px * 4)
@@ -232,20 +244,44 @@ class TwoChannelBatch:
         # whole batch on one GPU of 288 GB); otherwise one pair of buffers refilled inside run() frame by frame
         self.resident = bool(resident)
         n_buf = len(self.mine) if self.resident else 1
-        self.raw = [(ctx.alloc(px * 8), ctx.alloc(px * 8)) for _ in range(max(n_buf, 1))]
+        rows = self.n + (1 if scene == "c3" else 0)                    # c3: one more pulse, consumed by the DPCA pulse shift
+        self._alloc = [(ctx.alloc(rows * self.n * 8), ctx.alloc(rows * self.n * 8)) for _ in range(max(n_buf, 1))]
+        # what the focuser reads: the buffers themselves, or (c3) rx1[1:], rx2[:-1] as views
+        self.raw = [(_Ptr(a.ptr + (self.n * 8 if scene == "c3" else 0)), _Ptr(b.ptr)) for a, b in self._alloc]
         self._prepared = False
 
     # -- one frame -------------------------------------------------------------------------------------------
-    def synth_frame(self, f, bufs):
-        """Stand-in for frame f's two echo channels: device-resident complex noise, seeds per (frame, channel)."""
-        self.ctx.fill_noise(bufs[0], self.px, self.seed_base + 2 * f)
-        self.ctx.fill_noise(bufs[1], self.px, self.seed_base + 2 * f + 1)
+    def synth_frame(self, f, slot):
+        """Frame f's two echo channels into buffer pair `slot`: device-resident complex noise with seeds per (frame, channel),
+        or the C3 scene with its movers advanced to frame f (scene="c3")."""
+        if self.scene == "noise":
+            self.ctx.fill_noise(self.raw[slot][0], self.px, self.seed_base + 2 * f)
+            self.ctx.fill_noise(self.raw[slot][1], self.px, self.seed_base + 2 * f + 1)
+            return
+        from . import radar
+        from .echo import synth_device
+        k, n = self.k, self.n
+        n_pulses = n + 1
+        t_int = n_pulses / k["PRF"]
+        t_vec = np.linspace(-t_int / 2, t_int / 2, n_pulses)
+        p_tx, v_tx = radar.orbit_track(t_vec, k)
+        v_dir = v_tx / np.linalg.norm(v_tx, axis=1, keepdims=True)
+        t_start = 2 * k["R0"] / k["C"] - n / k["FS"] / 2                       # the focuser's window (radar.scaled_constants)
+        t_fast = t_start + np.linspace(0, n / k["FS"], n)                      # the generators' linspace grid (:113), n samples
+        for ch, off in enumerate((-k["d_rx"] / 2, k["d_rx"] / 2)):
+            first = True
+            for targets, vel in radar.c3_scene(f):
+                p0 = np.array([[t["position"][0] * self.scene_scale, t["position"][1] * self.scene_scale, t["position"][2]] for t in targets])
+                amp = np.sqrt(np.array([t["rcs"] for t in targets], dtype=np.float64))
+                synth_device(self.ctx, 1, p0, np.asarray(vel, dtype=np.float64), t_vec, p_tx, p_tx + v_dir * off, amp, t_fast,
+                             k["Kr"], k["T_p"], k["C"], k["FC"], out=self._alloc[slot][ch], accumulate=not first)
+                first = False
 
     def prepare(self):
         """Synthesise this rank's echoes (resident mode): call before the clock starts."""
         if self.resident and not self._prepared:
             for i, f in enumerate(self.mine):
-                self.synth_frame(f, self.raw[i])
+                self.synth_frame(f, i)
             self.ctx.sync()
         self._prepared = True
 
@@ -311,7 +347,7 @@ class TwoChannelBatch:
             if i < len(self.mine):
                 bufs = self.raw[i] if self.resident else self.raw[0]
                 if not self.resident:
-                    self.synth_frame(self.mine[i], bufs)
+                    self.synth_frame(self.mine[i], 0)
                 self.focus_frame(bufs, mine_ptr)
                 self.write_slot(mine_ptr)
             else:                                                   # pad round: zeros, never a stale slot
@@ -340,6 +376,6 @@ class TwoChannelBatch:
         return out
 
     def close(self):
-        for b in (self.s1, self.s2, self.masked, self.d_stack, self.d_max, *self.outs.values(), *(x for pair in self.raw for x in pair)):
+        for b in (self.s1, self.s2, self.masked, self.d_stack, self.d_max, *self.outs.values(), *(x for pair in self._alloc for x in pair)):
             b.release()
         self.plan.close()

@@ -32,6 +32,32 @@ def focus_args(n_rg=None, k=None):
     return (k["Lambda"], k["T_p"], k["Kr"], k["FS"], k["PRF"], k["V_eff"], k["R0"], t0)
 
 
+def scaled_constants(n_az, n_rg, chirp_fill=0.45, k=None):
+    """The reference radar with the pulse shortened so that the whole chirp fits an n_rg-sample window (the reference's 20 us
+    pulse needs 12000 of its 13200 samples): carrier, bandwidth, sample rate, PRF and geometry unchanged, Kr = BW / T_p follows.
+    What the power-of-two BASELINE configurations use when a scene has real point targets in it."""
+    k = dict(k or reference_constants())
+    window = n_rg / k["FS"]
+    k["T_p"] = min(k["T_p"], chirp_fill * window)
+    k["Kr"] = k["BW"] / k["T_p"]
+    k["t_start_fast"] = 2 * k["R0"] / C - window / 2
+    k["n_az"], k["n_rg"] = n_az, n_rg
+    return k
+
+
+def c3_scene(frame=0, frame_dt=0.1):
+    """SURVEY.md 8(d) C3 / C5 content: a 5 x 5 grid of stationary scatterers, one radial mover at 15 m/s (velocity_ship,
+    sar_ati_dcpa_sim_csa.py:184) and one slow mover, the movers advanced by frame * frame_dt seconds (VideoSAR cadence,
+    cf. sar_batch_sim.py:244-252).  Returns [(targets, velocity), ...] as run_bistatic_physics_gpu takes them."""
+    grid = [{"position": [float(x), float(y), 0.0], "rcs": 100.0 + 10.0 * i} for i, (x, y) in
+            enumerate((gx, gy) for gx in (-60.0, -30.0, 0.0, 30.0, 60.0) for gy in (-1500.0, -750.0, 0.0, 750.0, 1500.0))]
+    groups = [(grid, [0.0, 0.0, 0.0])]
+    for p0, rcs, vel in (([20.0, -400.0, 0.0], 2000.0, [15.0, 0.0, 0.0]), ([-35.0, 700.0, 0.0], 1500.0, [2.0, 0.0, 0.0])):
+        t = frame * frame_dt
+        groups.append(([{"position": [p0[0] + vel[0] * t, p0[1] + vel[1] * t, p0[2] + vel[2] * t], "rcs": rcs}], vel))
+    return groups
+
+
 def orbit_track(t_vec, k=None):
     """Great-circle transmitter positions and velocities over the slow-time vector
     (sar_ati_dcpa_sim_csa.py:50-66), as [n x 3] arrays."""

@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _ffi
@@ -37,7 +39,7 @@ _plans = {}
 
 
 def _plan(ctx, n_r, n_p, prm):
-    key = (id(ctx), n_r, n_p) + tuple(getattr(prm, f) for f, _ in prm._fields_)
+    key = (id(ctx), n_r, n_p, os.environ.get("SARX_RDA_DIRECT")) + tuple(getattr(prm, f) for f, _ in prm._fields_)
     plan = _plans.get(key)
     if plan is None or plan.h is None:
         while len(_plans) >= 2:                       # plans hold several full-image buffers

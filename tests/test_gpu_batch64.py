@@ -148,6 +148,44 @@ def test_products_stack_holds_every_frames_three_planes():
     b2.close()
 
 
+def test_c3_scene_frames_against_the_oracle():
+    """scene="c3" (frame f = the C3 scene - 5 x 5 grid, a 15 m/s radial mover, a slow mover - with the
+    movers advanced by f * 0.1 s): the echoes the driver synthesises on the device are downloaded and focused by the
+    oracle in complex128; the frame's three planes in the product stack are held to the oracle's, and the radial mover's
+    ATI phase and its motion between frames are there."""
+    import sarx
+    from oracle import csa_oracle as orc
+    from sarx.batch import TwoChannelBatch
+    ctx = sarx.default_context()
+    n, frames = 2048, 3
+    b = TwoChannelBatch(ctx, n, frames, stack="products", scene="c3", scene_scale=0.25)
+    b.run()
+    ctx.sync()
+    st = b.stack()
+    peaks = []
+    for f in (0, 2):
+        rx1 = b._alloc[f][0].download(np.complex64, (n + 1, n))
+        rx2 = b._alloc[f][1].download(np.complex64, (n + 1, n))
+        r1, r2 = rx1[1:], rx2[:-1]                                       # :402-403
+        assert np.abs(r1).max() > 0 and np.abs(r1 - r2).max() > 1e-3 * np.abs(r1).max()
+        o1 = orc.sar_focus_csa_lean(r1, *b.focus_args, workers=8)[0].T   # [n_az x n_rg] like the stack planes
+        o2 = orc.sar_focus_csa_lean(r2, *b.focus_args, workers=8)[0].T
+        ref = orc.ati_dpca(o1, o2)
+        inside = ref["slc1_mag"] > 0.05 * ref["max_mag"] * (1 + 1e-4)
+        outside = ref["slc1_mag"] < 0.05 * ref["max_mag"] * (1 - 1e-4)
+        assert inside.sum() > 20
+        d = np.angle(np.exp(1j * (st[f, 0][inside].astype(np.float64) - ref["ati_phase"][inside])))
+        assert np.linalg.norm(d) / np.linalg.norm(ref["ati_phase"][inside]) < 1e-4
+        assert (st[f, 0][outside] == 0).all()
+        assert orc.rel_l2(st[f, 1], ref["slc1_mag"]) < 1e-4
+        assert orc.rel_l2(st[f, 2][inside], ref["dpca_mag"][inside]) < 1e-3      # difference of nearly equal images
+        assert np.abs(ref["ati_phase"][inside]).max() > 0.2              # the radial mover shows an ATI phase
+        mover = np.where(inside & (np.abs(ref["ati_phase"]) > 0.2), ref["slc1_mag"], 0)
+        peaks.append(np.unravel_index(np.argmax(mover), mover.shape))
+    assert peaks[0] != peaks[1]                                          # the mover has moved between frame 0 and frame 2
+    b.close()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

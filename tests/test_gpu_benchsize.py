@@ -57,6 +57,16 @@ def _download_cols(ctx, buf, n_az, n_rg, cols):
     return np.concatenate([download_block(ctx, buf.ptr, n_rg, 0, n_az, c, 1) for c in cols], axis=1)
 
 
+def _unpermute(p):
+    """Rows of the permuted range spectrum (include/sarx.h, SARX_PASS_RG_FFT_PHI2_PERM: P[(k % 16) * 1024 + k // 16] = X[k])
+    back to natural bin order."""
+    return np.ascontiguousarray(p.reshape(p.shape[0], 16, 1024).transpose(0, 2, 1)).reshape(p.shape[0], -1)
+
+
+def _permute(x):
+    return np.ascontiguousarray(x.reshape(x.shape[0], 1024, 16).transpose(0, 2, 1)).reshape(x.shape[0], -1)
+
+
 def _energy(ctx, buf, n, scratch):
     _, s = ctx.ati_dpca(buf, buf, n, 0.0, scratch)
     return s.real
@@ -96,6 +106,26 @@ def test_range_passes_16384_many_lines_per_workgroup(sx, ctx, n_az):
     # worst single row, so that one bad line cannot hide in the aggregate
     per_row = np.linalg.norm(gf - o3, axis=1) / np.linalg.norm(o3, axis=1)
     assert per_row.max() < 2 * PASS_TOL, (rows[int(per_row.argmax())], per_row.max())
+    # the sixteen-wave pair the unfused focus runs (range_wp.hip): spectrum in permuted order between the two launches
+    d_p, d_q = ctx.alloc(px * 8), ctx.alloc(px * 8)
+    plan.run_pass(_ffi.PASS_RG_FFT_PHI2_PERM, d_in, d_p)
+    plan.run_pass(_ffi.PASS_RG_IFFT_PHI3_PERM, d_p, d_q)
+    gp = _unpermute(_download_rows(ctx, d_p, n_rg, rows))
+    assert orc.rel_l2(gp, o2) < PASS_TOL
+    per_row = np.linalg.norm(gp - o2, axis=1) / np.linalg.norm(o2, axis=1)
+    assert per_row.max() < 2 * PASS_TOL, (rows[int(per_row.argmax())], per_row.max())
+    gq = _download_rows(ctx, d_q, n_rg, rows)
+    assert orc.rel_l2(gq, o3) < PASS_TOL
+    per_row = np.linalg.norm(gq - o3, axis=1) / np.linalg.norm(o3, axis=1)
+    assert per_row.max() < 2 * PASS_TOL, (rows[int(per_row.argmax())], per_row.max())
+    for i, r in enumerate(rows):                                # the inverse alone, from the oracle's own spectrum rows
+        upload_block(ctx, d_p.ptr, n_rg, r, 0, _permute(o2[i:i + 1].astype(np.complex64)))
+    plan.run_pass(_ffi.PASS_RG_IFFT_PHI3_PERM, d_p, d_q)
+    assert orc.rel_l2(_download_rows(ctx, d_q, n_rg, rows), o3) < PASS_TOL
+    plan.run_pass(_ffi.PASS_RG_FFT_PHI2_PERM, d_in, d_p)        # in place, both launches, as the unfused focus runs them
+    plan.run_pass(_ffi.PASS_RG_IFFT_PHI3_PERM, d_p, d_p)
+    np.testing.assert_array_equal(_download_rows(ctx, d_p, n_rg, rows), gq)
+    d_p.release(); d_q.release()
     # in place, as sarx_csa_focus_dev runs it
     plan.run_pass(_ffi.PASS_RG_FUSED_23, d_in, d_in)
     np.testing.assert_array_equal(_download_rows(ctx, d_in, n_rg, rows), gf)
@@ -157,6 +187,11 @@ def test_full_scene_sampled_rows_and_columns(sx, ctx, n):
     assert orc.rel_l2(gf, o3) < PASS_TOL
     per_row = np.linalg.norm(gf - o3, axis=1) / np.linalg.norm(o3, axis=1)
     assert per_row.max() < 2 * PASS_TOL, (rows[int(per_row.argmax())], per_row.max())
+    if n == 16384:      # the permuted-spectrum pair of the unfused focus (and of bench.py's roofline_rg_fft_phi2_pass), on the same rows
+        plan_f.run_pass(_ffi.PASS_RG_FFT_PHI2_PERM, y1, y2)
+        assert orc.rel_l2(_unpermute(_download_rows(ctx, y2, n, rows)), o2) < PASS_TOL
+        plan_f.run_pass(_ffi.PASS_RG_IFFT_PHI3_PERM, y2, y3)
+        assert orc.rel_l2(_download_rows(ctx, y3, n, rows), o3) < 2 * PASS_TOL
     # pass 4: azimuth IFFT, columns
     plan_f.run_pass(_ffi.PASS_AZ_IFFT, yf, img)
     o4 = orc.azimuth_ifft_cols(_download_cols(ctx, yf, n, n, cols))

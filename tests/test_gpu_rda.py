@@ -58,6 +58,40 @@ def test_rda_native_range_extent():
     _check(sarx.sar_focus_rda(phist, *args), rda.sar_focus_rda(phist, *args))
 
 
+def test_rda_7200_pulses_prime_factor_route():
+    """7200 pulses (the satellite scripts' count, sar_satellite_sim.py:83-85): the pulse-axis transforms run as 32 x 225
+    prime-factor launches with the Hamming window and both fftshifts folded into their row addresses."""
+    import sarx
+    phist, args = rda.rda_scene(160, 7200, seed=72)
+    _check(sarx.sar_focus_rda(phist, *args), rda.sar_focus_rda(phist, *args))
+
+
+def test_rda_native_size_direct_route_equals_padded_route(monkeypatch):
+    """The satellite script's own size, 13200 samples x 7200 pulses, device-resident: the direct route (one 19683-point
+    circular convolution per pulse + 32 x 225 prime-factor transforms: six launches) against the route through 32768-point
+    split lines and a 16384-row chirp-z (thirteen launches), which the oracle tests above pin at smaller sizes."""
+    import sarx
+    n_r, n_p = 13200, 7200
+    from oracle import csa_oracle as orc
+    k = orc.reference_radar_constants()
+    args = (k["Lambda"], k["T_p"], k["Kr"], k["FS"], k["PRF"], k["V_eff"], k["R0"])
+    ctx = sarx.default_context()
+    buf = ctx.alloc(n_p * n_r * 8)
+    ctx.fill_noise(buf, n_p * n_r, 4242)
+    d = sarx.DeviceArray(buf, (n_p, n_r))
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SARX_RDA_DIRECT", mode)
+        o = sarx.sar_focus_rda(d.T, *args, device_output=True)
+        outs[mode] = [o[0].download(np.float32, (n_p, n_r))] + [o[i].download(np.complex64, (n_p, n_r)) for i in (3, 4, 5)]
+        for i in (0, 3, 4, 5):
+            o[i].release()
+    for a, b, what in zip(outs["1"], outs["0"], ("image", "range compression", "range-Doppler map", "RCMC")):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        assert rel_l2(a, b) < 2e-5, what
+    d.release()
+
+
 def test_rda_view_input_and_no_intermediates():
     """raw.T (a view) as the scripts pass it; intermediates=False returns None for the three maps."""
     import sarx

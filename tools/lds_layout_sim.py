@@ -1,5 +1,10 @@
+"""Bank-conflict count of the four LDS crossings of range_mixed.hip for a line length N = R1 * R2 * R3 and each pad 0..16:
+    python tools/lds_layout_sim.py [N R1 R2 R3 T]        (default 13200 24 22 25 640)
+prints LDS cycles (with conflicts, conflict-free) of the write and the read side of every crossing; pick the pads with the
+smallest sums and put them into the MixCfg of that length."""
 import itertools
-N,R1,R2,R3,T=13200,24,22,25,640
+import sys
+N,R1,R2,R3,T=(int(x) for x in sys.argv[1:6]) if len(sys.argv) >= 6 else (13200,24,22,25,640)
 def conflicts(addrs_per_lane, write):
     """addrs: list over lanes (64) of element address (8-byte elements) or None (inactive). returns LDS cycles."""
     cyc=0

@@ -124,7 +124,11 @@ int main(int argc, char** argv) {
             const int ks = k < N / 2 ? k : k - N;
             const double f = ks * a.df;
             x[k] *= cis_rev_h(f * (c2[row].x * f + c2[row].y));
+#if WP_LAYOUT == 1
+            const float2 g = hs[((k / 16) / 64) * 1024 + (k % 16) * 64 + (k / 16) % 64];
+#else
             const float2 g = hs[(k % 16) * 1024 + k / 16];                // the permuted order
+#endif
             num += std::norm(cd(g.x, g.y) - x[k]); den += std::norm(x[k]);
         }
         worst_spec = fmax(worst_spec, sqrt(num / den));
@@ -145,8 +149,8 @@ int main(int argc, char** argv) {
     // ---- timing ----
     const double gb = 16.0 * elems / 1e9;
     auto rep = [&](const char* name, float ms) { printf("%-44s %7.3f ms  %7.1f GB/s  %5.1f %% of 8 TB/s\n", name, ms, gb / (ms * 1e-3), gb / (ms * 1e-3) / 80.0); fflush(stdout); };
-    printf("WP_PREFETCH=%d WP_HOIST=%d WP_NT=%d, %d lines\n", WP_PREFETCH, WP_HOIST, WP_NT, n_az);
-    for (int rep_i = 0; rep_i < 2; ++rep_i) {
+    printf("WP_PREFETCH=%d WP_HOIST=%d WP_NT=%d WP_ABL=%d WP_LAYOUT=%d, %d lines\n", WP_PREFETCH, WP_HOIST, WP_NT, WP_ABL, WP_LAYOUT, n_az);
+    for (int rep_i = 0; rep_i < 3; ++rep_i) {
         rep("wp  FFT+Phi2 (permuted out)", time_ms([&] { run("", 0, RG_FFT_PHI2, d_in, d_spec); }));
         rep("wp  IFFT+Phi3 (permuted in)", time_ms([&] { run("", 0, RG_IFFT_PHI3, d_spec, d_out); }));
         rep("wp  fused", time_ms([&] { run("", 0, RG_FUSED, d_in, d_out); }));
