@@ -26,17 +26,27 @@
 //   fused:                   forward . Phi_2 . inverse . Phi_3 in one launch (the spectrum never leaves the registers)
 //
 // One persistent 1024-thread workgroup per CU (complex cross image [16][1088] = 136 KiB), four waves per SIMD at
-// <= 128 VGPRs.  The one-direction kernels keep the NEXT line's samples in flight in 32 further VGPRs while the
-// current line is transformed: with one workgroup per CU and barriers the waves run in lockstep, so without it the
-// CU's memory pipe idles during the arithmetic (tools/overlapbench.hip: sequential = sum, prefetch = max).
+// <= 128 VGPRs.  The NEXT line's samples are kept in flight in 32 further VGPRs while the current line is transformed
+// (two bursts of eight loads inside the wave-private phase): with one workgroup per CU and barriers the waves run in
+// lockstep, so without it the CU's memory pipe idles during the arithmetic.  Three things decide whether that prefetch
+// pays (each measured, profiles/r03_rgbench_*.log): (1) vmcnt retires in order, so the per-row phase constants must come
+// through the scalar cache - as a vector load issued after the prefetch they made every wave wait for the whole prefetch
+// before Phi_2; (2) the first line is landed before the loop, otherwise the loop header's merged wait state is vmcnt(0) and
+// every line waits for the PREVIOUS line's stores (now vmcnt(16): the stores stay in flight); (3) one burst of sixteen
+// loads right after the cross exchange is slower than no prefetch at all, two bursts of eight are the fastest placement.
 #include <cstdlib>
 #include "csa_kernels.h"
 #include "fft_core.hpp"
 #include "phase.hpp"
 
+// Tuning switches.  The defaults are what tools/rgbench.hip measured best on MI355X (profiles/r03_rgbench_*.log: FFT+Phi2 0.73 ms,
+// IFFT+Phi3 0.74 ms against 0.755 / 0.775 without the prefetch and 0.78-0.80 for range_v2.hip on the same box).
 #ifndef WP_PREFETCH
-#define WP_PREFETCH 0        // one-direction kernels, next line's loads: 0 none, 1 one burst before the wave-private phase, 2 one burst at the
-#endif                       // top of the line, 3 four groups spread over the wave-private phase
+#define WP_PREFETCH 5        // next line's loads: 0 none, 1 one burst before the wave-private phase, 2 one burst at the top of the line,
+#endif                       // 3 four groups spread over the wave-private phase, 4 two groups in the head + two in it, 5 two bursts of eight (start / middle of it)
+#ifndef WP_WITH_FUSED
+#define WP_WITH_FUSED 0      // also build FFT.Phi2.IFFT.Phi3 in one launch on this structure (tools/rgbench.hip): 128 VGPRs cannot hold its twiddles
+#endif                       // (spills 28-156 B/lane) and it loses to range_fused_wl.hip (1.18-1.25 vs 1.09-1.12 ms), so the library does not ship it
 #ifndef WP_LAYOUT
 #define WP_LAYOUT 0          // spectrum order between the two passes: 0 = P[q*1024 + k2] (a wave's 8 KiB contiguous), 1 = P'[kf*1024 + q*64 + lane],
 #endif                       // k2 = lane + 64 kf (the sixteen waves of a workgroup fill each 8 KiB chunk together, like the natural-order side)
@@ -44,7 +54,7 @@
 #define WP_ABL 0             // ablation builds (tools/rgbench.hip): 1 = no arithmetic (loads, exchanges, stores only), 2 = no exchanges either
 #endif
 #ifndef WP_HOIST
-#define WP_HOIST 5           // bit 0: cross twiddles W_N^(t q) kept in registers (30), bit 1: W_1024^(l ka) (30), bit 2: W_64^(l_lo ke) (6)
+#define WP_HOIST 4           // bit 0: cross twiddles W_N^(t q) kept in registers (30), bit 1: W_1024^(l ka) (30), bit 2: W_64^(l_lo ke) (6)
 #endif
 #ifndef WP_NT
 #define WP_NT 3              // bit 0: nontemporal line loads, bit 1: nontemporal line stores
@@ -376,7 +386,9 @@ hipError_t launch_range_wp(int mode, const RangeArgs& a, int cus, hipStream_t st
         case RG_IFFT: return launch_wp<RG_IFFT>(a, cus, st);
         case RG_FFT_PHI2: return launch_wp<RG_FFT_PHI2>(a, cus, st);
         case RG_IFFT_PHI3: return launch_wp<RG_IFFT_PHI3>(a, cus, st);
+#if WP_WITH_FUSED
         case RG_FUSED: return launch_wp<RG_FUSED>(a, cus, st);
+#endif
     }
     return hipErrorInvalidValue;
 }

@@ -144,9 +144,21 @@ def phase_balance(slc1, slc2, *, ctx=None):
     return float(np.angle(r["sum_interf"]))
 
 
+def two_channel_workspace(ctx, n_az, n_rg):
+    """Device buffers for focus_ati_dpca(..., workspace=...): both images, the three product planes and the max slot,
+    allocated once and reused by every call of that size (a frame loop then allocates nothing).  release() each when done."""
+    n = int(n_az) * int(n_rg)
+    ws = {"slc1": ctx.alloc(n * 8), "slc2": ctx.alloc(n * 8), "d_max": ctx.alloc(_ffi.MAX_SLOT_BYTES)}
+    for k in ("ati_phase_masked", "slc1_mag", "dpca_mag"):
+        ws[k] = ctx.alloc(n * 4)
+    ws["shape"] = (int(n_az), int(n_rg))
+    return ws
+
+
 def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz,
                    prf_hz, platform_speed_mps, range_ref_m, t_start_fast, mask_frac=0.05, cal_phase=0.0, *,
-                   ctx=None, pulse_shift=True, return_slc2=True, unmasked_phase=False, device_output=False):
+                   ctx=None, pulse_shift=True, return_slc2=True, unmasked_phase=False, device_output=False,
+                   workspace=None, fetch_stats=True):
     """The reference script's processing section in one call
     (sar_ati_dcpa_sim_csa.py:402-419,447-449): pulse shift, CSA focus of both
     channels, ATI/DPCA products, 5 % magnitude mask.  Nothing visits the host between the steps; with DeviceArray
@@ -164,7 +176,10 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
     return_slc2=False   : channel 2's image is never written (the reference saves it, :457-461, hence the default)
     unmasked_phase=True : also "ati_phase", the unmasked np.angle(slc1*conj(slc2)) of :415 (one more launch)
     device_output=True  : the images and planes stay on the GPU ([N_az x N_rg] row-major DeviceBuffers; release() them),
-                          max_mag / sum_interf are still fetched (24 bytes)
+                          max_mag / sum_interf are still fetched (24 bytes) unless fetch_stats=False (then the call only
+                          enqueues: no host synchronisation at all; Context.ati_stats() fetches them later)
+    workspace           : two_channel_workspace(ctx, N_az, N_rg): buffers reused from call to call (with device_output the
+                          returned buffers ARE the workspace's - do not release them per call)
     """
     ctx = ctx or default_context()
     on_device = isinstance(raw_rx1, DeviceArray) and isinstance(raw_rx2, DeviceArray)
@@ -181,11 +196,17 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
             platform_speed_mps, range_ref_m, t_start_fast)
     plan = _get_plan(ctx, n_az, n_rg, args, _ffi.FUSE_RANGE)
     n = n_az * n_rg
-    bufs = {"slc1": ctx.alloc(n * 8), "slc2": ctx.alloc(n * 8), "d_max": ctx.alloc(_ffi.MAX_SLOT_BYTES)}
-    for k in ("ati_phase_masked", "slc1_mag", "dpca_mag"):
-        bufs[k] = ctx.alloc(n * 4)
+    if workspace is not None:
+        if workspace.get("shape") != (n_az, n_rg):
+            raise ValueError("workspace was made for another size")
+        bufs = {k: v for k, v in workspace.items() if k != "shape"}
+        keep = set(bufs)                                    # never released here
+    else:
+        bufs = {"slc1": ctx.alloc(n * 8), "slc2": ctx.alloc(n * 8), "d_max": ctx.alloc(_ffi.MAX_SLOT_BYTES)}
+        for k in ("ati_phase_masked", "slc1_mag", "dpca_mag"):
+            bufs[k] = ctx.alloc(n * 4)
+        keep = set()
     d_raw = None if on_device else ctx.alloc(n * 8)
-    keep = set()
     try:
         try:                                                # channel 1: image + max|image| out of the same launch
             plan.set_max_slot(bufs["d_max"])
@@ -224,7 +245,7 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
             else:                                           # mask inside the ATI launch, threshold from channel 1's focus
                 outs = {"ati_phase": bufs["ati_phase_masked"], "slc1_mag": bufs["slc1_mag"], "dpca_mag": bufs["dpca_mag"]}
                 ctx.ati_dpca_masked(bufs["slc1"], bufs["slc2"], n, cal_phase, bufs["d_max"], mask_frac, outs)
-        max_mag, sum_interf = ctx.ati_stats()               # the only host synchronisation of the chain
+        max_mag, sum_interf = ctx.ati_stats() if (fetch_stats or not device_output) else (None, None)   # the only host synchronisation of the chain
         ra, ca = plan.axes()
         res = {"range_axis": ra, "cross_range": ca, "max_mag": max_mag, "sum_interf": sum_interf, "fused_products": fused}
         names = ["slc1"] + (["slc2"] if (return_slc2 or not fused) else []) + ["slc1_mag", "dpca_mag", "ati_phase_masked"] + \

@@ -52,19 +52,26 @@ def kernel_asm(path, kernel):
 
 
 def loops(asm):
-    """(header label, [instructions]) for every innermost loop: from the header label to the last branch back to it."""
-    heads = [(i, l.split(":")[0]) for i, l in enumerate(asm) if "Inner Loop Header" in l]
+    """(header label, [instructions]) for every innermost loop: the header block and every block the compiler tags
+    "in Loop: Header=<that label>" (conditional blocks inside the loop included)."""
     out = []
-    for i, lab in heads:
-        # blocks of this loop: contiguous labelled blocks whose comment names this header, before or after it
-        member = lambda l: ("Header=" + lab.lstrip(".L") in l.replace("BB", "BB")) or l.startswith(lab + ":")
-        idx = [j for j, l in enumerate(asm) if l.startswith(".LBB") and (("Header=" + lab[2:]) in l or l.startswith(lab + ":"))]
+    for i, l in enumerate(asm):
+        if "Inner Loop Header" not in l:
+            continue
+        j = i
+        while not asm[j].startswith(".LBB"):
+            j -= 1
+        lab = asm[j].split(":")[0]                     # .LBB0_11
+        tag = "Header=" + lab[2:]                      # Header=BB0_11
         body = []
-        for j in idx:
-            k = j + 1
-            while k < len(asm) and not asm[k].startswith(".LBB"):
-                body.append(asm[k])
-                k += 1
+        for k, m in enumerate(asm):
+            starts = m.startswith(lab + ":") or ((m.startswith(".LBB") or m.lstrip().startswith("; %bb.")) and tag in m)
+            if not starts:
+                continue
+            q = k + 1
+            while q < len(asm) and not asm[q].startswith(".LBB") and not asm[q].lstrip().startswith("; %bb."):
+                body.append(asm[q])
+                q += 1
         out.append((lab, body))
     return out
 

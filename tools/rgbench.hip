@@ -2,6 +2,9 @@
 // kernels of csrc/range_wp.hip against a host fp64 FFT on a few lines, and their launch times beside range_v2.hip and
 // range_fused_wl.hip on the same 16384 x 16384 image.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -ffp-contract=on [-DWP_PREFETCH=.. -DWP_HOIST=.. -DWP_NT=..] tools/rgbench.hip -o tools/rgbench.bin
+#ifndef WP_WITH_FUSED
+#define WP_WITH_FUSED 1
+#endif
 #include "../nis-sar-amtigmti-video_amd/csrc/range_wp.hip"
 #include "../nis-sar-amtigmti-video_amd/csrc/range_v2.hip"
 #include "../nis-sar-amtigmti-video_amd/csrc/range_fused_wl.hip"
