@@ -48,6 +48,16 @@ __device__ __forceinline__ FixPhase phi3_seed(int j0, int step, double2 c3, doub
     const double d0 = tau - t0, h = (double)step * dt;
     return make_fix(fma(c3.x, tau, c3.y * d0 * d0), h * fma(c3.y, 2.0 * d0 + h, c3.x), 2.0 * c3.y * h * h);
 }
+// One double2 of a per-row table through the SCALAR cache (p is wave-uniform).  vmcnt retires in order, so a vector load
+// of the row constants issued after the next line's prefetch would make the wave wait for the whole prefetch right there
+// (the compiler emits a vector load: it cannot prove the table is not written by the kernel).
+__device__ __forceinline__ double2 sload_double2(const double2* p) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    const unsigned long long lo = ((unsigned long long)r[1] << 32) | r[0], hi = ((unsigned long long)r[3] << 32) | r[2];
+    return make_double2(__longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
+}
 // direct forms (one fp64 evaluation per sample): any line length, no progression needed
 __device__ __forceinline__ cf phi2_at(int ks, double2 c2, double df) {
     const double f = (double)ks * df;

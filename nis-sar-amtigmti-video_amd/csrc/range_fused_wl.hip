@@ -107,16 +107,19 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));                   // keep addresses per-line (no hoisting out of the loop + spilling)
         const int w = t >> 6, l = t & 63;
-        const cf* __restrict__ src = a.in + (size_t)row * N;
         cf* __restrict__ dst = a.out + (size_t)row * N;
 
         cf v[32];
+        const cf* __restrict__ src = a.in + (size_t)row * N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float4 q4 = ld16<false>(src + 2 * t + r * M);
             v[r] = make_float2(q4.x, q4.y);
             v[16 + r] = make_float2(q4.z, q4.w);
         }
+        // the row's phase constants through the scalar cache, behind the line's own loads (their latency covers it): as vector
+        // loads next to their use their latency was exposed twice per line
+        const double2 c2 = sload_double2(a.c2 + row), c3 = sload_double2(a.c3 + row);
         // forward radix-16 over n1, then twiddle W_N^(n2 q)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -130,7 +133,6 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
         sub1024_r32<false>(v, li, img, wp);
         // Phi_2: v[r] is bin k = (2w+h) + 16 i + 512 r; r >= 16 are the negative frequencies
         {
-            const double2 c2 = a.c2[row];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 FixPhase q0 = phi2_seed(2 * w + (l >> 5) + 16 * li + half * (8192 - N), 512, c2, a.df);
@@ -153,7 +155,6 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
         }
         // Phi_3 / N and store: v[b*16 + n1] = N * x[n1*1024 + 2t + b]
         {
-            const double2 c3 = a.c3[row];
             const float sc = a.inv_n;
             FixPhase q0 = phi3_seed(2 * t, M, c3, a.dt, a.t_start, a.t0);
             FixPhase q1 = phi3_seed(2 * t + 1, M, c3, a.dt, a.t_start, a.t0);

@@ -15,6 +15,10 @@
 #include "fft_mixed.hpp"
 #include "phase.hpp"
 
+#ifndef MIX_PREFETCH
+#define MIX_PREFETCH 1       // FFT . x . IFFT modes: the next line's first-stage inputs are loaded during this line's inverse half (two bursts)
+#endif
+
 namespace sarx {
 
 // Exchange layouts.  A direction runs radices (RA, RB, RC); between its stages the line crosses LDS twice, and each crossing
@@ -26,8 +30,9 @@ namespace sarx {
 //       N/RC = RA RB elements:  (j div RA) * PITCH + (j mod RA) + RA r;   the last stage reads  j' + r' * PITCH
 // The pitches carry a few pad elements (picked with a bank-conflict count of every access: worst case 1.9x the
 // conflict-free LDS cycles on the strided reads of crossing 1, about 3 us of LDS time per 13200-sample line in all).
-template <int N_, int R1_, int R2_, int R3_, int T_, int P1_, int P2_, int P3_, int P4_> struct MixCfg {
-    static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_, T = T_;
+// NPF_: how many of the R1 first-stage samples per thread are prefetched for the next line (the rest is loaded at the top of the line)
+template <int N_, int R1_, int R2_, int R3_, int T_, int P1_, int P2_, int P3_, int P4_, int NPF_ = R1_> struct MixCfg {
+    static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_, T = T_, NPF = NPF_;
     static_assert(R1 * R2 * R3 == N, "radices must multiply to the line length");
     static_assert(N / R1 <= T && N / R2 <= T && N / R3 <= T, "one butterfly per thread and stage");
     static constexpr int RMAX = (R1 > R2 ? (R1 > R3 ? R1 : R3) : (R2 > R3 ? R2 : R3));
@@ -81,23 +86,50 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
     // accumulator (phase.hpp), the in-between bins are evaluated directly.
     constexpr int HALF = (N + 1) / 2;
     constexpr int R_LO = (HALF - G3) / G3, R_HI = (HALF + G3 - 1) / G3;
+    // With one workgroup per CU and barriers between the stages the waves run in lockstep: without a prefetch the CU's memory
+    // pipe idles through the whole transform.  The next line's R1 first-stage samples per thread wait in registers instead,
+    // requested in two bursts during the inverse half (after the mid-line vector loads of RG_CONV's filter spectrum: vmcnt
+    // retires in order, a load issued behind the prefetch would wait for all of it).
+    constexpr bool PRE = MIX_PREFETCH && FWD && BWD;
+    const size_t in_ld = (MODE == RG_CONV) ? a.conv_in_ld : (size_t)N;
+    auto load_first_stage = [&](cf* dstv, const cf* p, int t, int r0, int r1) {
+#pragma unroll
+        for (int r = 0; r < R1; ++r)
+            if (r >= r0 && r < r1) {
+                if constexpr (MODE == RG_CONV) dstv[r] = (t + r * G1 < a.conv_valid) ? ld8<false>(p + t + r * G1) : make_float2(0.f, 0.f);
+                else dstv[r] = ld8<false>(p + t + r * G1);
+            }
+    };
+    constexpr int NPF = C::NPF;
+    cf nxt[PRE ? NPF : 1];
+    if constexpr (PRE) {
+        if ((int)blockIdx.x < a.n_az && (int)threadIdx.x < G1)
+            load_first_stage(nxt, a.in + (size_t)range_row(a, blockIdx.x) * in_ld, threadIdx.x, 0, NPF);
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the loop header's merged wait state is then the back edge's (stores stay in flight)
+    }
     for (int line = blockIdx.x; line < a.n_az; line += gridDim.x) {
         const int row = range_row(a, line);
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));                     // per-line addresses: nothing hoisted out of the line loop and spilled
-        const cf* __restrict__ src = a.in + (size_t)row * (MODE == RG_CONV ? a.conv_in_ld : (size_t)N);
+        const cf* __restrict__ src = a.in + (size_t)row * in_ld;
         cf* __restrict__ dst = a.out + (size_t)row * (MODE == RG_CONV ? a.conv_out_ld : (size_t)N);
+        const int next_line = line + gridDim.x;
+        const cf* nsrc = a.in + (size_t)range_row(a, next_line < a.n_az ? next_line : line) * in_ld;   // the last line re-reads itself (never used)
         cf v[C::RMAX];
         if (line != (int)blockIdx.x) __syncthreads();   // the previous line's last reads of the image are finished
+        // the row's phase constants through the scalar cache (as vector loads next to their use their latency was exposed per line)
+        double2 c2 = make_double2(0, 0), c3 = c2;
+        if constexpr (MODE == RG_FFT_PHI2 || MODE == RG_FUSED) c2 = sload_double2(a.c2 + row);
+        if constexpr (MODE == RG_IFFT_PHI3 || MODE == RG_FUSED) c3 = sload_double2(a.c3 + row);
         if constexpr (FWD) {
             // stage 1: radix R1, NS = 1, straight from HBM (8 bytes per lane, consecutive lanes consecutive samples)
             if (t < G1) {
-                if constexpr (MODE == RG_CONV) {         // the line is shorter than the transform: zeros beyond it, never read
+                if constexpr (PRE) {
 #pragma unroll
-                    for (int r = 0; r < R1; ++r) v[r] = (t + r * G1 < a.conv_valid) ? ld8<false>(src + t + r * G1) : make_float2(0.f, 0.f);
+                    for (int r = 0; r < NPF; ++r) v[r] = nxt[r];
+                    load_first_stage(v, src, t, NPF, R1);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < R1; ++r) v[r] = ld8<false>(src + t + r * G1);
+                    load_first_stage(v, src, t, 0, R1);      // RG_CONV: the line is shorter than the transform, zeros beyond it are never read
                 }
                 mix::dft_any<R1, false>(v);
                 cross1_write<R1, C::PITCH_F1>(v, t, lds);
@@ -131,7 +163,6 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
                         for (int r = 0; r < R3; ++r) dst[t + r * G3] = v[r];
                     }
                 } else {
-                    const double2 c2 = a.c2[row];
                     FixPhase lo = phi2_seed(t, G3, c2, a.df);                        // numpy.fft.fftfreq order: k, then k - N
                     FixPhase hi = phi2_seed(t + R_HI * G3 - N, G3, c2, a.df);
 #pragma unroll
@@ -158,6 +189,7 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
             }
             if constexpr (FWD) __syncthreads();         // forward stage 3's reads of the image are finished
             if (t < G3) cross1_write<R3, C::PITCH_I1>(v, t, lds);
+            if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, 0, NPF / 2); }
             __syncthreads();
             // stage 2: radix R2, NS = R3
             if (t < G2) {
@@ -167,6 +199,7 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
             }
             __syncthreads();
             if (t < G2) cross2_write<R3, R2, C::PITCH_I2>(v, t, lds);
+            if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, NPF / 2, NPF); }
             __syncthreads();
             // stage 3: radix R1, NS = R3 R2; thread t ends with samples n = t + r G1
             if (t < G1) {
@@ -184,7 +217,6 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
 #pragma unroll
                     for (int r = 0; r < R1; ++r) dst[t + r * G1] = make_float2(v[r].x * s, v[r].y * s);
                 } else {
-                    const double2 c3 = a.c3[row];
                     FixPhase q = phi3_seed(t, G1, c3, a.dt, a.t_start, a.t0);
 #pragma unroll
                     for (int r = 0; r < R1; ++r) {
@@ -206,7 +238,7 @@ using Mix13200 = MixCfg<13200, 24, 22, 25, 640, 0, 8, 1, 3>;   // pads from the 
 // line fits LDS (<= 20480) 27^3 is the one whose three stages all have <= 768 butterflies (729): twelve waves, three per
 // SIMD, 168 VGPRs.  (19200 = 32 * 24 * 25 needs 800 butterflies in one stage: thirteen waves, four on one SIMD, 128 VGPRs,
 // and spilled 32 of them.)
-using Mix19683 = MixCfg<19683, 27, 27, 27, 768, 0, 2, 0, 2>;
+using Mix19683 = MixCfg<19683, 27, 27, 27, 768, 0, 2, 0, 2, 19>;     // 19 of the 27 rows prefetched: every row a 13200-sample line has samples in (27 rows spill at 168 VGPRs)
 
 template <class C, int MODE> static hipError_t launch_mixed(const RangeArgs& a, int cus, hipStream_t st) {
     auto k = range_mixed_kernel<C, MODE>;

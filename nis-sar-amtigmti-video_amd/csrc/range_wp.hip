@@ -66,7 +66,9 @@ namespace wp {
 constexpr int N = 16384, M = 1024, THREADS = 1024;
 constexpr int ROW = 1088;                                         // complex elements per row of the cross image (1024 + room for the padded private image)
 constexpr size_t LDS_BYTES = (size_t)16 * ROW * sizeof(cf);       // 139264
-constexpr int PF = 65, PI = 66;                                   // row pitch of the private [16 x 64] exchange image, forward / inverse (bank-conflict free each way)
+constexpr int PF = 65, PI = 65;                                   // row pitch of the private [16 x 64] exchange image: the compiler pairs the accesses into ds_read2_b64 /
+                                                                  // ds_write2_b64 (16-lane groups over 32 banks), for which an odd pitch is conflict-free both ways (66 on the inverse:
+                                                                  // SQ_LDS_BANK_CONFLICT = 22 % of its LDS cycles, profiles/r03_pmc_range_kernels.json)
 
 __device__ __forceinline__ cf cmulc(cf a, cf b) {                 // a * conj(b)
     return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
@@ -76,16 +78,6 @@ __device__ __forceinline__ void powers16(cf w1, cf* w) {
     w[1] = w1;
 #pragma unroll
     for (int k = 2; k < 16; ++k) w[k] = cmul(w[k / 2], w[k - k / 2]);
-}
-// One double2 of a per-row table through the SCALAR cache (p is wave-uniform).  vmcnt retires in order, so a vector load
-// of the row constants issued after the next line's prefetch would make the wave wait for the whole prefetch right there
-// (the compiler emits a vector load: it cannot prove the table is not written by the kernel).
-__device__ __forceinline__ double2 sload_double2(const double2* p) {
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    u4 r;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
-    const unsigned long long lo = ((unsigned long long)r[1] << 32) | r[0], hi = ((unsigned long long)r[3] << 32) | r[2];
-    return make_double2(__longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
 }
 __device__ __forceinline__ cf cis_neg(int num, float inv_den) { return cis_frac(-(float)num * inv_den); }   // exp(-2 pi i num/den), exact fp32 argument
 

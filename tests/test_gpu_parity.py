@@ -218,6 +218,33 @@ def test_two_channel_end_to_end(sx):
         np.testing.assert_array_equal(lean[key], res[key])
 
 
+def test_two_channel_facade_on_a_reused_workspace(sx, ctx):
+    """focus_ati_dpca with device arrays in, device_output and a two_channel_workspace: nothing is allocated or fetched per
+    call (fetch_stats=False: the call only enqueues), the planes equal the default call's bit for bit, and a second frame
+    through the same workspace overwrites them."""
+    from sarx.engine import DeviceArray
+    (r1, r2), k = orc.point_scene(256, 1024, seed=11, clutter_db=-20.0, two_channel=True)
+    args = orc.focus_args(k)
+    ref = sx.focus_ati_dpca(r1, r2, *args, pulse_shift=False, ctx=ctx)
+    ws = sx.two_channel_workspace(ctx, 256, 1024)
+    d1, d2 = DeviceArray(ctx.to_device(r1), r1.shape), DeviceArray(ctx.to_device(r2), r2.shape)
+    out = sx.focus_ati_dpca(d1, d2, *args, pulse_shift=False, ctx=ctx, device_output=True, workspace=ws, fetch_stats=False)
+    assert out["max_mag"] is None and out["fused_products"] and out["slc1_mag"] is ws["slc1_mag"]
+    mx, sm = ctx.ati_stats()
+    assert mx == ref["max_mag"] and sm == ref["sum_interf"]
+    for key in ("slc1_mag", "dpca_mag", "ati_phase_masked"):
+        np.testing.assert_array_equal(out[key].download(np.float32, r1.shape).T, ref[key])
+    np.testing.assert_array_equal(out["slc1"].download(np.complex64, r1.shape).T, ref["slc1"])
+    out2 = sx.focus_ati_dpca(d2, d1, *args, pulse_shift=False, ctx=ctx, device_output=True, workspace=ws)     # channels swapped
+    swapped = sx.focus_ati_dpca(r2, r1, *args, pulse_shift=False, ctx=ctx)
+    np.testing.assert_array_equal(out2["dpca_mag"].download(np.float32, r1.shape).T, swapped["dpca_mag"])
+    assert out2["max_mag"] == swapped["max_mag"]
+    with pytest.raises(ValueError):
+        sx.focus_ati_dpca(r1[:128], r2[:128], *args, pulse_shift=False, ctx=ctx, workspace=ws)
+    for b in (d1, d2, *(v for kk, v in ws.items() if kk != "shape")):
+        b.release()
+
+
 def test_max_slot_and_ati_left_armed_together(sx, ctx):
     """A C caller may leave sarx_csa_plan_set_max_slot armed while the second channel's focus runs with
     sarx_csa_plan_set_ati: that focus reads the slot as its threshold and must neither clear nor re-reduce it
