@@ -19,12 +19,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--size", type=int, default=8192)
-    ap.add_argument("--stack", choices=("multilook", "magnitude"), default="multilook")
+    ap.add_argument("--stack", choices=("multilook", "magnitude", "products"), default="multilook")
+    ap.add_argument("--scene", choices=("noise", "c3"), default="noise", help="c3: SURVEY.md 8(d) C5's content, movers advanced by f * 0.1 s per frame")
     a = ap.parse_args()
     import sarx
     from sarx.batch import TwoChannelBatch
     ctx = sarx.Context(0)
-    b = TwoChannelBatch(ctx, a.size, a.frames, stack=a.stack)
+    b = TwoChannelBatch(ctx, a.size, a.frames, stack=a.stack, scene=a.scene)
     b.prepare()
     b.run()
     ctx.sync()
@@ -34,7 +35,7 @@ def main():
     dt = time.perf_counter() - t0
     print(json.dumps({"metric": "VideoSAR batch frames/sec (two-channel CSA focus + ATI/DPCA + mask, stack slot)",
                       "value": a.frames / dt, "unit": "frames/s", "n_gpus": 1, "batch_s": dt, "ms_per_frame": dt / a.frames * 1e3,
-                      "config": {"workload": f"{a.frames} frames x two-channel {a.size}x{a.size} complex64", "stack": a.stack}}))
+                      "config": {"workload": f"{a.frames} frames x two-channel {a.size}x{a.size} complex64", "stack": a.stack, "scene": a.scene}}))
 
 
 if __name__ == "__main__":
