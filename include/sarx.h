@@ -71,8 +71,8 @@ typedef struct {
 #define SARX_PASS_AZ_IFFT 4       /* :385 */
 #define SARX_PASS_RG_FUSED_23 23  /* passes 2 and 3 in one launch */
 /* Passes 2 and 3 with the range spectrum in the PERMUTED order the unfused focus keeps it in between its two range
- * launches (n_rg = 16384 only; SARX_ERR_UNSUPPORTED otherwise):  P[(k mod 16) * 1024 + k div 16] = X[k], k the natural
- * (numpy.fft.fftfreq) bin index.  The spectrum exists only between these two launches (:278-382 never hands it out), so its
+ * launches (n_rg = 16384 only; SARX_ERR_UNSUPPORTED otherwise):  with k the natural (numpy.fft.fftfreq) bin index, q = k mod 16 and
+ * k2 = k div 16,  P[(k2 div 64) * 1024 + q * 64 + (k2 mod 64)] = X[k].  The spectrum exists only between these two launches (:278-382 never hands it out), so its
  * storage order is free, and this one lets each launch run with a single workgroup-wide exchange (csrc/range_wp.hip). */
 #define SARX_PASS_RG_FFT_PHI2_PERM 12   /* natural-order line in, permuted spectrum out */
 #define SARX_PASS_RG_IFFT_PHI3_PERM 13  /* permuted spectrum in, natural-order line out */

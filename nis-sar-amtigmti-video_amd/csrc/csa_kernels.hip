@@ -40,6 +40,11 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
     cf* __restrict__ dst = a.out + (size_t)row * N;
 
     constexpr bool FWD_FIRST = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED);
+    // the row's phase constants are requested FIRST: vmcnt retires in order, so they arrive with the line itself; next to their
+    // use (mid-line) their latency was exposed once or twice per line
+    double2 c2 = make_double2(0, 0), c3 = c2;
+    if constexpr (MODE == RG_FFT_PHI2 || MODE == RG_FUSED) c2 = a.c2[row];
+    if constexpr (MODE == RG_IFFT_PHI3 || MODE == RG_FUSED) c3 = a.c3[row];
     cf v[P];
     if constexpr (FWD_FIRST) {
         using E = Edge<N, false>;
@@ -71,7 +76,6 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
             return;
         } else {
             // output bin of register (b, r) is t + T*m with m = b + (P/RL)*r; bins >= N/2 are negative frequencies
-            const double2 c2 = a.c2[row];
             constexpr int B = P / RL;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -109,7 +113,6 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
 #pragma unroll
         for (int i = 0; i < P; ++i) v[i] = make_float2(v[i].x * s, v[i].y * s);
     } else {
-        const double2 c3 = a.c3[row];
         FixPhase q = phi3_seed(t, T, c3, a.dt, a.t_start, a.t0);
         constexpr int B = P / RL;
 #pragma unroll

@@ -4,11 +4,13 @@
 // The spectrum of a range line exists only between the forward transform (+ Phi_2, :278-326) and the inverse
 // (+ Phi_3, :331-382); nothing else ever reads it, so its storage order is free.  With the order
 //
-//        P[q * 1024 + k2] = X[q + 16 k2]          (q = bin mod 16, k2 = bin div 16)
+//        P[kf * 1024 + q * 64 + lane] = X[q + 16 (lane + 64 kf)]        (q = bin mod 16; bin div 16 = lane + 64 kf)
 //
 // each direction needs ONE workgroup-wide exchange instead of two: the forward transform is decimation in frequency
-// over 16 x 1024 and stops where its wave-private 1024-point transforms end (wave q holds X[q + 16 k2], lanes along
-// k2: a 512-byte contiguous store per wave instruction), the inverse starts from exactly that arrangement and mirrors it.
+// over 16 x 1024 and stops where its wave-private 1024-point transforms end (wave q holds X[q + 16 k2] with k2 = lane + 64 kf
+// in register kf: a 512-byte contiguous store per wave instruction, the sixteen waves of the workgroup filling one 8 KiB
+// chunk per kf together, exactly like the natural-order side), the inverse starts from that arrangement and mirrors it.
+// (WP_LAYOUT=0 keeps a wave's 8 KiB contiguous instead, P[q*1024 + k2]: same speed out of place, 2-4 % slower in place.)
 //
 //   forward (FFT + Phi_2):   load x[n1*1024 + t]  (thread t of 1024, n1 = 0..15: 8 B per lane, 512 B per wave instruction)
 //                            radix-16 over n1, twiddle W_N^(t q)                               -> y_q[t]
@@ -42,13 +44,14 @@
 // Tuning switches.  The defaults are what tools/rgbench.hip measured best on MI355X (profiles/r03_rgbench_*.log: FFT+Phi2 0.73 ms,
 // IFFT+Phi3 0.74 ms against 0.755 / 0.775 without the prefetch and 0.78-0.80 for range_v2.hip on the same box).
 #ifndef WP_PREFETCH
-#define WP_PREFETCH 5        // next line's loads: 0 none, 1 one burst before the wave-private phase, 2 one burst at the top of the line,
-#endif                       // 3 four groups spread over the wave-private phase, 4 two groups in the head + two in it, 5 two bursts of eight (start / middle of it)
+#define WP_PREFETCH 6        // next line's loads: 0 none, 1 one burst before the wave-private phase, 2 one burst at the top of the line,
+#endif                       // 3 four groups spread over the wave-private phase, 4 two groups in the head + two in it, 5 two bursts of eight (start / middle of it),
+                             // 6 the same two bursts taking every other access each
 #ifndef WP_WITH_FUSED
 #define WP_WITH_FUSED 0      // also build FFT.Phi2.IFFT.Phi3 in one launch on this structure (tools/rgbench.hip): 128 VGPRs cannot hold its twiddles
 #endif                       // (spills 28-156 B/lane) and it loses to range_fused_wl.hip (1.18-1.25 vs 1.09-1.12 ms), so the library does not ship it
 #ifndef WP_LAYOUT
-#define WP_LAYOUT 0          // spectrum order between the two passes: 0 = P[q*1024 + k2] (a wave's 8 KiB contiguous), 1 = P'[kf*1024 + q*64 + lane],
+#define WP_LAYOUT 1          // spectrum order between the two passes: 0 = P[q*1024 + k2] (a wave's 8 KiB contiguous), 1 = P'[kf*1024 + q*64 + lane],
 #endif                       // k2 = lane + 64 kf (the sixteen waves of a workgroup fill each 8 KiB chunk together, like the natural-order side)
 #ifndef WP_ABL
 #define WP_ABL 0             // ablation builds (tools/rgbench.hip): 1 = no arithmetic (loads, exchanges, stores only), 2 = no exchanges either
@@ -313,10 +316,18 @@ __global__ __launch_bounds__(wp::THREADS, 4) void range_wp_kernel(RangeArgs a) {
         // the next line's loads: where[] says after which point of the line they are issued
         auto prefetch_all = [&]() { if (have_next) load_regs<NTL, STRIDE>(nxt, nsrc); };
         auto group = [&](int gidx) { if (have_next) load_regs<NTL, STRIDE>(nxt, nsrc, gidx, gidx + 1); };
+        auto parity = [&](int odd) {                  // every other access: each burst spans the whole line
+            if (have_next) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if ((i & 1) == odd) nxt[i] = ld8<NTL>(nsrc + i * STRIDE);
+            }
+        };
         auto hook = [&](int point) {
             if constexpr (WP_PREFETCH == 3) group(point);
             if constexpr (WP_PREFETCH == 4) { if (point == 1) group(2); if (point == 3) group(3); }
             if constexpr (WP_PREFETCH == 5) { if (point == 0) { group(0); group(1); } if (point == 2) { group(2); group(3); } }
+            if constexpr (WP_PREFETCH == 6) { if (point == 0) parity(0); if (point == 2) parity(1); }
         };
         if constexpr (WP_PREFETCH == 2) prefetch_all();
         if constexpr (WP_PREFETCH == 4) group(0);

@@ -17,7 +17,7 @@ COMM_ID_BYTES = 128
 OUT_AZ_MAJOR, OUT_RG_MAJOR, FUSE_RANGE = 0, 1, 2
 PASS_AZ_FFT_PHI1, PASS_RG_FFT_PHI2, PASS_RG_IFFT_PHI3, PASS_AZ_IFFT, PASS_RG_FUSED_23 = 1, 2, 3, 4, 23
 PASS_TEST_RG_FFT, PASS_TEST_RG_IFFT = 100, 101
-PASS_RG_FFT_PHI2_PERM, PASS_RG_IFFT_PHI3_PERM = 12, 13      # n_rg = 16384: spectrum order P[(k % 16) * 1024 + k // 16] = X[k]
+PASS_RG_FFT_PHI2_PERM, PASS_RG_IFFT_PHI3_PERM = 12, 13      # n_rg = 16384: spectrum order P[(k // 16 // 64) * 1024 + (k % 16) * 64 + (k // 16) % 64] = X[k]
 
 
 class SarxError(RuntimeError):

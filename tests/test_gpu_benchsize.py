@@ -58,13 +58,16 @@ def _download_cols(ctx, buf, n_az, n_rg, cols):
 
 
 def _unpermute(p):
-    """Rows of the permuted range spectrum (include/sarx.h, SARX_PASS_RG_FFT_PHI2_PERM: P[(k % 16) * 1024 + k // 16] = X[k])
-    back to natural bin order."""
-    return np.ascontiguousarray(p.reshape(p.shape[0], 16, 1024).transpose(0, 2, 1)).reshape(p.shape[0], -1)
+    """Rows of the permuted range spectrum (include/sarx.h, SARX_PASS_RG_FFT_PHI2_PERM:
+    P[(k // 16 // 64) * 1024 + (k % 16) * 64 + (k // 16) % 64] = X[k]) back to natural bin order."""
+    out = np.ascontiguousarray(p.reshape(p.shape[0], 16, 16, 64).transpose(0, 1, 3, 2)).reshape(p.shape[0], -1)
+    k = np.arange(16384)
+    assert np.array_equal(out[0], p[0][(k // 16 // 64) * 1024 + (k % 16) * 64 + (k // 16) % 64])      # the header's formula, literally
+    return out
 
 
 def _permute(x):
-    return np.ascontiguousarray(x.reshape(x.shape[0], 1024, 16).transpose(0, 2, 1)).reshape(x.shape[0], -1)
+    return np.ascontiguousarray(x.reshape(x.shape[0], 16, 64, 16).transpose(0, 1, 3, 2)).reshape(x.shape[0], -1)
 
 
 def _energy(ctx, buf, n, scratch):

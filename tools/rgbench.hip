@@ -5,7 +5,7 @@
 #ifndef WP_WITH_FUSED
 #define WP_WITH_FUSED 1
 #endif
-#include "../nis-sar-amtigmti-video_amd/csrc/range_wp.hip"
+#include "../nis-sar-amtigmti-video_amd/csrc/range_wp.hip"   // defines the WP_* defaults it was not given
 #include "../nis-sar-amtigmti-video_amd/csrc/range_v2.hip"
 #include "../nis-sar-amtigmti-video_amd/csrc/range_fused_wl.hip"
 
@@ -69,8 +69,13 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
+    // argv[2]: the spectrum / output images start this many KiB into their allocations (does the relative placement of the read and the
+    // write stream matter?)
+    const size_t off_elems = (argc > 2 ? (size_t)atol(argv[2]) : 0) * 128;
     float2 *d_in, *d_spec, *d_out;
-    CK(hipMalloc(&d_in, elems * 8)); CK(hipMalloc(&d_spec, elems * 8)); CK(hipMalloc(&d_out, elems * 8));
+    CK(hipMalloc(&d_in, elems * 8)); CK(hipMalloc(&d_spec, elems * 8 + (64 << 20))); CK(hipMalloc(&d_out, elems * 8 + (64 << 20)));
+    d_spec += off_elems; d_out += 2 * off_elems;
+    printf("output offset %zu KiB; d_in %p d_spec %p d_out %p\n", off_elems / 128, (void*)d_in, (void*)d_spec, (void*)d_out);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, d_in, elems, 12345u);
     CK(hipDeviceSynchronize());
 
@@ -156,6 +161,8 @@ int main(int argc, char** argv) {
     for (int rep_i = 0; rep_i < 3; ++rep_i) {
         rep("wp  FFT+Phi2 (permuted out)", time_ms([&] { run("", 0, RG_FFT_PHI2, d_in, d_spec); }));
         rep("wp  IFFT+Phi3 (permuted in)", time_ms([&] { run("", 0, RG_IFFT_PHI3, d_spec, d_out); }));
+        rep("wp  FFT+Phi2 then IFFT+Phi3 in place (x2)", time_ms([&] { run("", 0, RG_FFT_PHI2, d_out, d_out); run("", 0, RG_IFFT_PHI3, d_out, d_out); }) / 2);
+        rep("wp  FFT+Phi2 d_in -> d_out (other offset)", time_ms([&] { run("", 0, RG_FFT_PHI2, d_in, d_out); }));
         rep("wp  fused", time_ms([&] { run("", 0, RG_FUSED, d_in, d_out); }));
         rep("wp  fused in place", time_ms([&] { run("", 0, RG_FUSED, d_out, d_out); }));
         rep("v2  FFT+Phi2", time_ms([&] { run("", 1, RG_FFT_PHI2, d_in, d_spec); }));
