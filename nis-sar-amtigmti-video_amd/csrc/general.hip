@@ -657,25 +657,48 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a,
     const double c_a = sc.y * a.inv_dr, c_b = r0 * a.inv_dr;      // u = r_j / (s dr) - r_0 / dr;  1 / (x_b - x_a) = 1 / (s dr)
     const double fd2 = a.fd[k] * a.fd[k];
     const cf* row = a.in + (size_t)k * a.n_r;
+    const int last = a.n_r - 1;
+    // A thread's four pixels first request everything the estimated bracket jc = floor(u) needs (its two positions and its two
+    // samples), then decide: written pixel by pixel with the two correction loops in between, a pixel was three dependent
+    // loads deep and the four ran one after the other - the launch was bound by that latency chain, not by its traffic.
+    // The loops stay, for the pixel whose estimate is one off (fp rounding of u at an integer), as the rare slow path.
+    double rj[4], xa[4], xb[4];
+    int jc[4];
+    cf p[4], q[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j = blockIdx.x * 1024 + m * 256 + threadIdx.x;
+        rj[m] = a.r_axis[j < a.n_r ? j : last];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        int c = (int)floor(fma(rj[m], c_a, -c_b));
+        c = c < 0 ? 0 : (c > last - 1 ? last - 1 : c);
+        jc[m] = c;
+        xa[m] = a.r_axis[c]; xb[m] = a.r_axis[c + 1];
+        p[m] = row[c]; q[m] = row[c + 1];
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int j = blockIdx.x * 1024 + m * 256 + threadIdx.x;
         if (j >= a.n_r) continue;
-        const double rj = a.r_axis[j];
         cf y = make_float2(0.f, 0.f);
-        if (rj >= x_first && rj <= x_last) {
-            int j0 = (int)floor(fma(rj, c_a, -c_b));
-            if (j0 < 0) j0 = 0;
-            if (j0 > a.n_r - 2) j0 = a.n_r - 2;
-            while (j0 > 0 && a.r_axis[j0] * s > rj) --j0;
-            while (j0 < a.n_r - 2 && a.r_axis[j0 + 1] * s <= rj) ++j0;
-            const float f = (float)((rj - a.r_axis[j0] * s) * c_a);
-            const cf p = row[j0], q = row[j0 + 1];
-            y = make_float2(fmaf(f, q.x - p.x, p.x), fmaf(f, q.y - p.y, p.y));
+        if (rj[m] >= x_first && rj[m] <= x_last) {
+            double x0 = xa[m] * s;
+            cf pp = p[m], qq = q[m];
+            int j0 = jc[m];
+            if ((j0 > 0 && x0 > rj[m]) || (j0 < last - 1 && xb[m] * s <= rj[m])) {      // estimate one off: np.interp's bracket by search
+                while (j0 > 0 && a.r_axis[j0] * s > rj[m]) --j0;
+                while (j0 < last - 1 && a.r_axis[j0 + 1] * s <= rj[m]) ++j0;
+                x0 = a.r_axis[j0] * s;
+                pp = row[j0]; qq = row[j0 + 1];
+            }
+            const float f = (float)((rj[m] - x0) * c_a);
+            y = make_float2(fmaf(f, qq.x - pp.x, pp.x), fmaf(f, qq.y - pp.y, pp.y));
         }
         const size_t i = (size_t)k * a.n_r + j;
         if (rc_out) rc_out[i] = y;
-        a.out[i] = cmul(y, cis_rev(-0.5 * a.k_ac * rj * fd2));
+        a.out[i] = cmul(y, cis_rev(-0.5 * a.k_ac * rj[m] * fd2));
     }
 }
 __global__ __launch_bounds__(256) void rda_mag_kernel(const cf* in, float* mag, size_t n) {
