@@ -54,6 +54,10 @@ def parse_args(argv=None):
                          "magnitude (256 MiB/frame: loads xGMI), products (masked ATI phase, |slc1|, DPCA magnitude: 768 MiB/frame, "
                          "SURVEY.md 8(e)'s product stack), both = multilook + magnitude, all = the three one after the other")
     ap.add_argument("--batch-reps", type=int, default=3, help="timed repetitions of the batch64 block (the median is reported; keeps the GPU busy long enough to be sampled)")
+    ap.add_argument("--config3", action="store_true",
+                    help="add a `config3_two_channel` block: BASELINE config 3 (two-channel --batch-size^2 scene: 2 x CSA focus + ATI/DPCA + "
+                         "5 %% mask through sarx.focus_ati_dpca, device-resident) with its own cpu_baseline (oracle: 2 x focus + the "
+                         "sar_ati_dcpa_sim_csa.py:414-419,447-449 expressions)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank reports (rank, local rank, world) and exits before touching the GPU")
     return ap.parse_args(argv)
@@ -94,6 +98,74 @@ def cpu_baseline(size, workers=1, scaled=True):
     return {"value": 1.0 / (best * scale), "unit": "frames/s", "cores": workers, "kind": "port",
             "sample": f"{n}x{n} complex64 noise frame, oracle/csa_oracle.sar_focus_csa_lean (NumPy/scipy.fft, "
                       f"{workers} thread(s) of {os.cpu_count()}), {best:.2f} s, {how}"}
+
+
+def cpu_baseline_two_channel(n_full, workers, n_sample):
+    """Oracle ("port") for BASELINE config 3: 2 x sar_focus_csa_lean + the ATI / DPCA / mask expressions of
+    sar_ati_dcpa_sim_csa.py:414-419,447-449 on an n_sample^2 two-channel noise frame, scaled by sample count to n_full^2."""
+    import numpy as np
+    from oracle import csa_oracle as orc
+    k = orc.scaled_radar(n_sample, n_sample)
+    rng = np.random.default_rng(0)
+    chans = []
+    for _ in range(2):
+        raw = np.empty((n_sample, n_sample), dtype=np.complex64)
+        for i0 in range(0, n_sample, 1024):
+            blk = rng.standard_normal((min(1024, n_sample - i0), n_sample, 2), dtype=np.float32)
+            raw[i0:i0 + blk.shape[0]] = blk[..., 0] + 1j * blk[..., 1]
+        chans.append(raw)
+    t = time.perf_counter()
+    s1 = orc.sar_focus_csa_lean(chans[0], *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)[0]
+    s2 = orc.sar_focus_csa_lean(chans[1], *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)[0]
+    t_focus = time.perf_counter() - t
+    t = time.perf_counter()
+    ati_phase = np.angle(s1 * np.conj(s2))            # :414-415
+    slc1_mag = np.abs(s1)                             # :416
+    dpca_mag = np.abs(s1 - s2)                        # :418-419
+    ati_phase[~(slc1_mag > slc1_mag.max() * 0.05)] = 0   # :447-449
+    t_prod = time.perf_counter() - t
+    assert np.isfinite(dpca_mag).all()
+    scale = (n_full / n_sample) ** 2
+    return {"value": 1.0 / ((t_focus + t_prod) * scale), "unit": "frames/s", "cores": workers, "kind": "port",
+            "sample": f"two-channel {n_sample}x{n_sample} complex64 noise frame: oracle focus x2 {t_focus:.2f} s ({workers} thread(s) of "
+                      f"{os.cpu_count()}) + ATI/DPCA/mask expressions (NumPy, 1 thread) {t_prod:.2f} s" +
+                      (f", scaled x{scale:.0f} by sample count to {n_full}x{n_full}" if scale != 1 else ", the full frame")}
+
+
+def run_config3(sarx, ctx, n, frames=10, cpu=True):
+    """BASELINE config 3 through the function a maintainer calls (sarx.focus_ati_dpca), device arrays in, products left on the device."""
+    from sarx import radar
+    from sarx.engine import DeviceArray
+    px = n * n
+    raw = [ctx.alloc(px * 8), ctx.alloc(px * 8)]
+    for i, b in enumerate(raw):
+        ctx.fill_noise(b, px, 31 + i)
+    d1, d2 = (DeviceArray(b, (n, n), owner=False) for b in raw)
+    ws = sarx.two_channel_workspace(ctx, n, n)
+    args = radar.focus_args(n)
+    call = lambda: sarx.focus_ati_dpca(d1, d2, *args, ctx=ctx, pulse_shift=False, return_slc2=False, device_output=True, workspace=ws,
+                                       fetch_stats=False)
+    for _ in range(2):
+        call()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        call()
+    ctx.sync()
+    ms = (time.perf_counter() - t0) / frames * 1e3
+    mx, _ = ctx.ati_stats()
+    assert mx > 0
+    for b in (*raw, *(v for k, v in ws.items() if k != "shape")):
+        b.release()
+    blk = {"metric": "two-channel frames/sec (2 x CSA focus + ATI/DPCA + 5 % mask)", "value": 1e3 / ms, "unit": "frames/s", "ms_per_frame": ms,
+           "workload": f"two-channel {n}x{n} complex64, both echoes resident in HBM (BASELINE config 3), {frames} frames through "
+                       "sarx.focus_ati_dpca(device arrays, device_output, reused workspace): products out of channel 2's last azimuth launch"}
+    if cpu:
+        blk["cpu_baseline"] = cpu_baseline_two_channel(n, 1, min(n, 4096))
+        mt = min(os.cpu_count() or 1, 32)
+        if mt > 1:
+            blk["cpu_baseline_threads"] = cpu_baseline_two_channel(n, mt, n)
+    return blk
 
 
 def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, stack):
@@ -413,6 +485,8 @@ def main():
                 blk["collective"] = collective or "none (one rank)"
                 line["batch64" if st == "multilook" else "batch64_" + st] = blk
 
+    if rank == 0 and world == 1 and a.config3:
+        line["config3_two_channel"] = run_config3(sarx, ctx, a.batch_size, cpu=not a.no_cpu)
     if rank == 0:
         if world == 1 and not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(n)

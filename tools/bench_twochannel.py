@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE config 3: two-channel n x n scene, CSA focus of both channels + ATI/DPCA on one MI355X.
-    python3 tools/bench_twochannel.py [size=8192 | native] [frames=10] [fused | masked | two-pass] [--json FILE] [--cpu]
+    python3 tools/bench_twochannel.py [size=8192 | native] [frames=10] [fused | facade | masked | two-pass] [--json FILE]
 Echoes are device-resident noise; prints ms per frame, frames/s, and the ATI/DPCA kernel's GB/s
-against its 28 B/pixel algorithmic traffic.  --json writes one JSON object (the numbers + with --cpu a
-cpu_baseline: the oracle's two focuses + the :414-419,447-449 expressions on this box's host cores)."""
+against its 28 B/pixel algorithmic traffic.  --json writes one JSON object with the numbers.  (The CPU baseline
+of this configuration is `bench.py --config3`: only bench.py's cpu_baseline leg runs the oracle.)"""
 import json
 import os
 import sys
@@ -14,12 +14,8 @@ if "--json" in sys.argv:
     i = sys.argv.index("--json")
     json_path = sys.argv[i + 1]
     del sys.argv[i:i + 2]
-want_cpu = "--cpu" in sys.argv
-if want_cpu:
-    sys.argv.remove("--cpu")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "nis-sar-amtigmti-video_amd"))
 import sarx  # noqa: E402
 from sarx import _ffi, radar  # noqa: E402
@@ -113,40 +109,6 @@ else:
           f"= {28.0 * px / ati_ms / 1e6 / 8000.0:.3f} of the 8 TB/s HBM peak")
 
 
-def cpu_two_channel(n_full, workers, n_sample):
-    """Oracle ("port"): 2 x sar_focus_csa_lean + the ATI/DPCA/mask expressions on an n_sample^2 two-channel noise frame."""
-    import numpy as np
-    from oracle import csa_oracle as orc
-    k = orc.scaled_radar(n_sample, n_sample)
-    rng = np.random.default_rng(0)
-    chans = []
-    for _ in range(2):
-        raw = np.empty((n_sample, n_sample), dtype=np.complex64)
-        for i0 in range(0, n_sample, 1024):
-            blk = rng.standard_normal((min(1024, n_sample - i0), n_sample, 2), dtype=np.float32)
-            raw[i0:i0 + blk.shape[0]] = blk[..., 0] + 1j * blk[..., 1]
-        chans.append(raw)
-    t = time.perf_counter()
-    s1 = orc.sar_focus_csa_lean(chans[0], *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)[0]
-    s2 = orc.sar_focus_csa_lean(chans[1], *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)[0]
-    t_focus = time.perf_counter() - t
-    t = time.perf_counter()
-    ati_interf = s1 * np.conj(s2)                     # :414
-    ati_phase = np.angle(ati_interf)                  # :415
-    slc1_mag = np.abs(s1)                             # :416
-    dpca_mag = np.abs(s1 - s2)                        # :418-419
-    mask = slc1_mag > slc1_mag.max() * 0.05           # :447
-    ati_phase[~mask] = 0                              # :448-449
-    t_prod = time.perf_counter() - t
-    assert np.isfinite(dpca_mag).all()
-    scale = (n_full / n_sample) ** 2
-    tot = (t_focus + t_prod) * scale
-    return {"value": 1.0 / tot, "unit": "frames/s", "cores": workers, "kind": "port",
-            "sample": f"two-channel {n_sample}x{n_sample} complex64 noise frame: oracle focus x2 {t_focus:.2f} s + ATI/DPCA/mask expressions "
-                      f"(NumPy, 1 thread) {t_prod:.2f} s, {workers} focus thread(s) of {os.cpu_count()}" +
-                      (f", scaled x{scale:.0f} by sample count to {n_full}x{n_full}" if scale != 1 else ", the full frame")}
-
-
 if json_path:
     rec = {"metric": "two-channel frames/sec (2 x CSA focus + ATI/DPCA + 5 % mask)", "value": 1e3 / ms, "unit": "frames/s", "ms_per_frame": ms,
            "config": {"workload": f"two-channel {n_az}x{n_rg} complex64, both echoes resident in HBM (BASELINE config 3)", "form": how},
@@ -157,11 +119,6 @@ if json_path:
         rec["channel2_focus_with_products_ms"] = ati_ms
     else:
         rec["ati_dpca_launch"] = {"ms": ati_ms, "GBps": 28.0 * px / ati_ms / 1e6, "frac_of_8TBps": 28.0 * px / ati_ms / 1e6 / 8000.0}
-    if want_cpu and not native:
-        rec["cpu_baseline"] = cpu_two_channel(n, 1, min(n, 4096))
-        mt = min(os.cpu_count() or 1, 32)
-        if mt > 1:
-            rec["cpu_baseline_threads"] = cpu_two_channel(n, mt, n)
     with open(json_path, "w") as fh:
         json.dump(rec, fh)
     print(json.dumps(rec))

@@ -10,8 +10,9 @@ prof() {  # tag, program args...
   rm -rf $O/prof_$tag
 }
 timeout -k 10 900 python bench.py --steps 20 --warmup 3 --stack all > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
-for s in 4096 8192; do timeout -k 10 300 python bench.py --size $s --steps 40 --warmup 5 --no-batch > $O/bench_$s.json 2>/dev/null; echo "bench $s rc $?"; done
-for m in fused facade masked two-pass; do timeout -k 10 400 python tools/bench_twochannel.py 8192 10 $m --json $O/twochannel_$m.json $( [ $m = fused ] && echo --cpu ) >> $O/twochannel.log 2>&1; echo "tc $m rc $?"; done
+timeout -k 10 300 python bench.py --size 4096 --steps 40 --warmup 5 --no-batch > $O/bench_4096.json 2>/dev/null; echo "bench 4096 rc $?"
+timeout -k 10 400 python bench.py --size 8192 --steps 40 --warmup 5 --no-batch --config3 > $O/bench_8192.json 2>/dev/null; echo "bench 8192 rc $?"   # + config 3 with its CPU baseline
+for m in fused facade masked two-pass; do timeout -k 10 400 python tools/bench_twochannel.py 8192 10 $m --json $O/twochannel_$m.json >> $O/twochannel.log 2>&1; echo "tc $m rc $?"; done
 for m in fused facade; do timeout -k 10 300 python tools/bench_twochannel.py native 10 $m --json $O/native_twochannel_$m.json >> $O/native_twochannel.log 2>&1; echo "ntc $m rc $?"; done
 cat $O/twochannel.log $O/native_twochannel.log | grep -v "^{"
 timeout -k 10 300 python tools/bench_batch64.py > $O/batch64.log 2>&1; echo "rc $?"; cat $O/batch64.log
