@@ -54,7 +54,12 @@ __device__ __forceinline__ FixPhase phi3_seed(int j0, int step, double2 c3, doub
 __device__ __forceinline__ double2 sload_double2(const double2* p) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     u4 r;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    // the address is wave-uniform by construction; readfirstlane tells the compiler so (it does not move a VGPR pair into the
+    // "s" operand by itself when its own analysis calls the value divergent)
+    const unsigned long long pv = (unsigned long long)p;
+    const unsigned long long ps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv);
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(ps) : "memory");
     const unsigned long long lo = ((unsigned long long)r[1] << 32) | r[0], hi = ((unsigned long long)r[3] << 32) | r[2];
     return make_double2(__longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
 }
