@@ -156,9 +156,6 @@ hipError_t az_pfa7200_run(bool inv, const float2* src, size_t src_ld, int cols, 
 // range_wp.hip: sixteen-wave range passes at 16384 samples with the spectrum in permuted order between FFT+Phi2 and IFFT+Phi3
 bool range_wp_supported(int n_rg);
 hipError_t launch_range_wp(int mode, const RangeArgs& a, int cus, hipStream_t st);
-// the same structure for 8192-sample lines, FFT . Phi2 . IFFT . Phi3 in one launch (natural order in and out)
-bool range_wp8_supported(int n_rg);
-hipError_t launch_range_wp8_fused(const RangeArgs& a, int cus, hipStream_t st);
 
 // products.hip
 struct AtiArgs {

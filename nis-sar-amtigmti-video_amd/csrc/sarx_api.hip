@@ -609,9 +609,6 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
     // impl 3 (default for the fused launch at 16384): wave-private sub-transforms
     if (mode == RG_FUSED && range_fused_wl_supported(p->n_rg) && (c->range_impl == 3 || c->range_impl == 0))
         return launch_range_fused_wl(a, c->cus, c->stream);
-    // 8192-sample lines: eight waves per line, wave-private 1024-point transforms (range_wp.hip); SARX_RANGE_IMPL=1 keeps the Stockham kernel
-    if (mode == RG_FUSED && range_wp8_supported(p->n_rg) && (c->range_impl == 4 || c->range_impl == 0))
-        return launch_range_wp8_fused(a, c->cus, c->stream);
     return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->cus, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
 }
 
