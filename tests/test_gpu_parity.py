@@ -455,6 +455,14 @@ def test_longest_lines_each_pass(sx, ctx, n_az, n_rg):
     assert orc.rel_l2(run(_ffi.PASS_RG_IFFT_PHI3, s2), s3) < 5e-6
     assert orc.rel_l2(run(_ffi.PASS_RG_FUSED_23, s1), s3) < 5e-6
     assert orc.rel_l2(run(_ffi.PASS_AZ_IFFT, s3), s4) < 5e-6
+    if n_rg == 16384:      # the permuted-spectrum pair of the unfused focus, whole image (fewer lines than persistent workgroups)
+        unperm = lambda p: np.ascontiguousarray(p.reshape(n_az, 16, 16, 64).transpose(0, 1, 3, 2)).reshape(n_az, -1)
+        perm = lambda x: np.ascontiguousarray(x.reshape(n_az, 16, 64, 16).transpose(0, 1, 3, 2)).reshape(n_az, -1)
+        assert orc.rel_l2(unperm(run(_ffi.PASS_RG_FFT_PHI2_PERM, s1)), s2) < 5e-6
+        assert orc.rel_l2(run(_ffi.PASS_RG_IFFT_PHI3_PERM, perm(s2)), s3) < 5e-6
+    else:
+        with pytest.raises(sx.SarxError):
+            plan.run_pass(_ffi.PASS_RG_FFT_PHI2_PERM, d_a, d_b)
     for fuse in (True, False):
         img = sx.sar_focus_csa(raw, *args, fuse_range=fuse)[0]
         assert orc.rel_l2(img, s4.T) < 1e-5
