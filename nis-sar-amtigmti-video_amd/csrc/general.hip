@@ -649,6 +649,8 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_kernel(RdaArgsDev a, cf* 
 // only (s, 1/s, the span of the migrated axis) comes from a table built at plan creation, so a pixel costs one fused
 // multiply-add for its fractional position instead of three fp64 divisions (0.86 -> ms at 13200 x 7200: profiles/r03_f_*).
 // The bracketing sample is still checked against the actual positions r_axis[j] * s, as np.interp would find it.
+struct __attribute__((aligned(8))) RcmcD2 { double a, b; };       // two neighbouring positions / samples as ONE 16-byte access
+struct __attribute__((aligned(8))) RcmcF4 { float x, y, z, w; };  // (8-byte aligned: the hardware takes an unaligned dwordx4)
 __global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a, cf* rc_out) {
     const int k = blockIdx.y;
     const double2 sc = a.rowc[k];
@@ -675,8 +677,10 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a,
         int c = (int)floor(fma(rj[m], c_a, -c_b));
         c = c < 0 ? 0 : (c > last - 1 ? last - 1 : c);
         jc[m] = c;
-        xa[m] = a.r_axis[c]; xb[m] = a.r_axis[c + 1];
-        p[m] = row[c]; q[m] = row[c + 1];
+        const RcmcD2 xr = *reinterpret_cast<const RcmcD2*>(a.r_axis + c);
+        const RcmcF4 pq = *reinterpret_cast<const RcmcF4*>(row + c);
+        xa[m] = xr.a; xb[m] = xr.b;
+        p[m] = make_float2(pq.x, pq.y); q[m] = make_float2(pq.z, pq.w);
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
