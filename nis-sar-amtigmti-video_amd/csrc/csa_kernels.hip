@@ -2,6 +2,7 @@
 // passes, each an FFT fused with the phase multiply that follows it in the
 // reference (sar_ati_dcpa_sim_csa.py:233-385).  fftshift/ifftshift pairs of the
 // reference cancel: phases are evaluated at natural-order bins.
+#include <type_traits>
 #include "csa_kernels.h"
 #include "fft_core.hpp"
 #include "phase.hpp"
@@ -311,7 +312,17 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                 // |x|^2 summed over the `look` consecutive columns of this row (consecutive lanes): fixed xor tree, bitwise
                 // reproducible; the lane of the group's first column stores the row-wise partial
                 float pw = fmaf(x.x, x.x, x.y * x.y);
-                for (int off = 1; off < a.look; off <<= 1) pw += __shfl_xor(pw, off, 64);
+                // the xor tree over lanes 1, 2, 4, 8 as DPP moves (quad permutes, then row_half_mirror / row_mirror: after the first
+                // two steps a quad's lanes hold equal sums, so the mirrors pair the same partial sums the xor would): the same
+                // additions in the same order as __shfl_xor - bit-identical - without 4 ds_bpermute per sample
+                auto dpp_add = [&](auto ctrl) {
+                    pw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pw), decltype(ctrl)::value, 0xF, 0xF, false));
+                };
+                if (a.look > 1) dpp_add(std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+                if (a.look > 2) dpp_add(std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+                if (a.look > 4) dpp_add(std::integral_constant<int, 0x141>{});      // row_half_mirror
+                if (a.look > 8) dpp_add(std::integral_constant<int, 0x140>{});      // row_mirror
+                for (int off = 16; off < a.look; off <<= 1) pw += __shfl_xor(pw, off, 64);
                 if ((c & (a.look - 1)) == 0) a.look_part[rowo * (size_t)(a.n_rg / a.look) + col / a.look] = pw;
             } else if constexpr (EPI == AZ_EPI_SCALE || EPI == AZ_EPI_PROCOL) {
                 if constexpr (EPI == AZ_EPI_PROCOL) {      // only the cropped part of the line is wanted
