@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 202
+#define SARX_VERSION 203   /* 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
