@@ -17,9 +17,11 @@
 //   Phi_3 / N, store x[n1*1024 + n2]  (16 B per lane)
 //
 // Residency: one persistent 512-thread workgroup per CU (complex cross image [16][1088] = 136 KiB),
-// two waves per SIMD, 164 VGPRs.  The register file, not LDS, rules out two lines per CU: the same
-// body capped at 128 VGPRs (real/imaginary parts exchanged separately through a 68 KiB image, two
-// workgroups per CU) spills 308 B/lane and runs 2.0 ms against 1.4 ms (measured).
+// two waves per SIMD, 233 VGPRs (122 of them the thread-constant twiddles hoisted out of the line loop).
+// The register file, not LDS, rules out two lines per CU: the same body capped at 128 VGPRs spills
+// (real/imaginary split image, round 1: 308 B/lane, 2.0 vs 1.4 ms; the sixteen-wave structure of
+// range_wp.hip, round 3: 28-156 B/lane, 1.18-1.25 vs 1.09-1.12 ms).  Bound by instruction
+// issue at two waves per SIMD (3 760 vector instructions per 32 samples), not by its exchanges or by HBM.
 #include <cstdlib>
 #include "csa_kernels.h"
 #include "fft_core.hpp"
