@@ -53,6 +53,9 @@ def parse_args(argv=None):
                     help="batch64 stack slot: 16x16 multilook (1 MiB/frame at 8192^2; headline), full-resolution "
                          "magnitude (256 MiB/frame: loads xGMI), products (masked ATI phase, |slc1|, DPCA magnitude: 768 MiB/frame, "
                          "SURVEY.md 8(e)'s product stack), both = multilook + magnitude, all = the three one after the other")
+    ap.add_argument("--batch-scene", choices=("noise", "c3"), default="noise",
+                    help="batch64 content: device noise (bandwidth does not depend on content) or SURVEY.md 8(d) C5's scene - the C3 point-target "
+                         "scene with its movers advanced by f * 0.1 s per frame, synthesised on the device before the clock starts")
     ap.add_argument("--batch-reps", type=int, default=3, help="timed repetitions of the batch64 block (the median is reported; keeps the GPU busy long enough to be sampled)")
     ap.add_argument("--config3", action="store_true",
                     help="add a `config3_two_channel` block: BASELINE config 3 (two-channel --batch-size^2 scene: 2 x CSA focus + ATI/DPCA + "
@@ -172,7 +175,7 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
     """BASELINE config 5 through the shared device driver; returns the block for the JSON line (rank 0) or None."""
     from sarx.batch import TwoChannelBatch
     b = TwoChannelBatch(ctx, a.batch_size, a.batch_frames, world, rank, stack=stack, looks=LOOKS, rccl=use_rccl and world > 1,
-                        host_comm=None if (use_rccl or world == 1) else host_comm)
+                        host_comm=None if (use_rccl or world == 1) else host_comm, scene=a.batch_scene)
     b.prepare()                                                  # echoes of this rank's frames resident in HBM before the clock
     b.run()                                                      # warm-up batch
     times = []
@@ -210,7 +213,8 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
     blk = {"metric": "VideoSAR batch frames/sec (two-channel CSA focus + ATI/DPCA + mask, stack all-gather)",
            "value": a.batch_frames / dt, "unit": "frames/s", "batch_s": dt, "batch_s_all": [round(x, 5) for x in times], "scaling": "strong", "n_gpus": world,
            "workload": f"{a.batch_frames} frames x two-channel {a.batch_size}x{a.batch_size} complex64 (BASELINE config 5), "
-                       f"frame f -> rank f mod {world}, every frame's two echo channels resident in HBM before the clock starts",
+                       f"frame f -> rank f mod {world}, every frame's two echo channels resident in HBM before the clock starts" +
+                       (" (device noise)" if a.batch_scene == "noise" else " (C3 point-target scene, movers advanced by f * 0.1 s)"),
            "stack": what + f", {slot_bytes / 2**20:.0f} MiB per frame, gathered in place once per round of {world} frame(s)",
            "per_frame": per_frame, "gather_bytes_per_rank_per_round": slot_bytes,
            "gather_s_per_round_at_one_xgmi_link": link_s}
