@@ -134,6 +134,10 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
     }
 }
 
+// One workgroup per line group, not persistent: a persistent form of this kernel (2 workgroups per CU walking the lines, <= 128
+// VGPRs, no scratch) ran 8192-sample lines 3-12 % SLOWER in every mode (fused 0.362-0.376 vs 0.348-0.351 ms, FFT+Phi2 0.244-0.250
+// vs 0.216-0.220 ms at 8192 x 8192; profiles/r03_p_range_persistent_ab.log, ABBA order) - with a few waves per line a fresh
+// dispatch staggers the workgroups of a CU, the persistent pair falls into step.
 template <int N, int MODE> static hipError_t launch_range(const RangeArgs& a, hipStream_t st) {
     using CFG = RangeCfg<N>;
     auto k = range_pass_kernel<N, MODE>;
