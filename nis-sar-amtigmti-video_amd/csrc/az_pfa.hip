@@ -18,6 +18,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "csa_kernels.h"
@@ -53,24 +54,48 @@ static_assert(N1 * P == N && RA * RB == L, "factorisation");
 // that stages the next tile in 26 VGPRs and passes it through LDS (tools/rader_prefetch.patch: 0.432-0.437 vs 0.445 ms; with the
 // arithmetic alone at 0.268 ms, loads add 0.05, stores 0.06, both 0.17 - tools/overlapbench.hip shows the same for any
 // workgroup that runs its waves in lockstep on 128 KiB tiles).
-template <int W>
-__global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
+// TWO: two workgroups per CU, so that one's butterflies run during the other's loads and stores (with one 768-thread workgroup the
+// waves are in lockstep and the two add up, see above).  The [312 x W] image alone is 78 KiB, so the tables shrink to 16-bit row
+// numbers (1.2 KiB) and the spectrum of w' comes through the scalar cache (a wave holds two butterflies j, j + 1: one 16-byte
+// scalar load per r, picked per half-wave); six waves per SIMD means 80 VGPRs, which the last 24-point butterfly only fits when it
+// is staged by hand (below).
+template <int W, bool TWO>
+__device__ __forceinline__ void rader313_body(const PfaArgs& a, cf* lds) {
     using namespace pfa;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cf* lds = reinterpret_cast<cf*>(smem_raw);                   // [312][W]
-    unsigned* tin = reinterpret_cast<unsigned*>(lds + (size_t)L * W);   // 23 g^q rows of the source, in bytes
-    unsigned* tout = tin + L;                                            // g^-m rows of the intermediate, in bytes
-    cf* bsp = reinterpret_cast<cf*>(tout + L);                           // spectrum of w': read mid-tile, and a global load there would
+    typedef typename std::conditional<TWO, unsigned short, unsigned>::type tab_t;
+    tab_t* tin = reinterpret_cast<tab_t*>(lds + (size_t)L * W);          // 23 g^q rows of the source: bytes, or row numbers (TWO)
+    tab_t* tout = tin + L;                                               // g^-m rows of the intermediate
+    cf* bsp = reinterpret_cast<cf*>(tout + L);                           // !TWO: spectrum of w': read mid-tile, and a global load there would
                                                                          // make the in-order vmcnt wait for everything issued before it
     const unsigned c = threadIdx.x % W, j = threadIdx.x / W;     // j in [0, 24)
     const unsigned col = blockIdx.x * W + c, n1 = blockIdx.y;
     const bool live = (int)col < a.in_cols;
     const unsigned colb = col * (unsigned)sizeof(cf);
-    for (int i = threadIdx.x; i < L; i += RA * W) { tin[i] = a.offin[i]; tout[i] = a.offu[i]; bsp[i] = a.bspec[i]; }
+    const unsigned pin = a.off0in / (unsigned)P, pu = a.off0u / (unsigned)P;    // bytes per row
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 bq[TWO ? RB : 1];
+    if constexpr (TWO) {
+        static_assert(!TWO || (W == 32 && RB == 13), "a wave holds butterflies j = 2w, 2w + 1");
+        for (int i = threadIdx.x; i < L; i += RA * W) { tin[i] = (tab_t)(a.offin[i] / pin); tout[i] = (tab_t)(a.offu[i] / pu); }
+        const unsigned long long pv = (unsigned long long)(a.bspec + 2 * (threadIdx.x / 64));
+        const unsigned long long ps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv);
+        // bins j + 24 r, r = 0..12: 192 bytes apart
+        asm volatile("s_load_dwordx4 %0, %13, 0x0\n\ts_load_dwordx4 %1, %13, 0xc0\n\ts_load_dwordx4 %2, %13, 0x180\n\t"
+                     "s_load_dwordx4 %3, %13, 0x240\n\ts_load_dwordx4 %4, %13, 0x300\n\ts_load_dwordx4 %5, %13, 0x3c0\n\t"
+                     "s_load_dwordx4 %6, %13, 0x480\n\ts_load_dwordx4 %7, %13, 0x540\n\ts_load_dwordx4 %8, %13, 0x600\n\t"
+                     "s_load_dwordx4 %9, %13, 0x6c0\n\ts_load_dwordx4 %10, %13, 0x780\n\ts_load_dwordx4 %11, %13, 0x840\n\t"
+                     "s_load_dwordx4 %12, %13, 0x900\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(bq[0]), "=&s"(bq[1]), "=&s"(bq[2]), "=&s"(bq[3]), "=&s"(bq[4]), "=&s"(bq[5]), "=&s"(bq[6]), "=&s"(bq[7]),
+                       "=&s"(bq[8]), "=&s"(bq[9]), "=&s"(bq[10]), "=&s"(bq[11]), "=&s"(bq[12])
+                     : "s"(ps) : "memory");
+    } else {
+        for (int i = threadIdx.x; i < L; i += RA * W) { tin[i] = a.offin[i]; tout[i] = a.offu[i]; bsp[i] = a.bspec[i]; }
+    }
     __syncthreads();
     const char* __restrict__ src = reinterpret_cast<const char*>(a.in);
     char* __restrict__ dst = reinterpret_cast<char*>(a.u);
-    const unsigned wrap = (unsigned)N * (a.off0in / (unsigned)P);         // bytes of 7199 source rows
+    const unsigned wrap = (unsigned)N * pin;                              // bytes of 7199 source rows
 
     cf v[RA];
     cf a0 = make_float2(0.f, 0.f), y0 = a0;
@@ -79,9 +104,9 @@ __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
         const unsigned b = n1 * a.off0in;
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            unsigned o = b + tin[j + RB * r];
+            unsigned o = b + (TWO ? __umul24((unsigned)tin[j + RB * r], pin) : (unsigned)tin[j + RB * r]);
             if (o >= wrap) o -= wrap;
-            v[r] = live ? ldnt(src + (o + colb), a.nt) : make_float2(0.f, 0.f);
+            v[r] = live ? ldnt(src + (o + colb), TWO || a.nt) : make_float2(0.f, 0.f);
         }
         if (j == 0 && live) a0 = *reinterpret_cast<const cf*>(src + (b + colb));          // n2 = 0: row 313 n1
         mix::dft_any<RA, false>(v);
@@ -96,8 +121,17 @@ __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
     mix::dft_any<RB, false>(v);
     // times the spectrum of w' (carries the 1/312 of the convolution); the DC bin also gives y[0] and takes a[0]
     if (j == 0) y0 = cadd(a0, v[0]);
+    if constexpr (TWO) {
+        const bool odd = (threadIdx.x & 32) != 0;
 #pragma unroll
-    for (int r = 0; r < RB; ++r) v[r] = cmul(v[r], bsp[j + RA * r]);
+        for (int r = 0; r < RB; ++r) {
+            const cf w = make_float2(__uint_as_float(odd ? bq[r].z : bq[r].x), __uint_as_float(odd ? bq[r].w : bq[r].y));
+            v[r] = cmul(v[r], w);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) v[r] = cmul(v[r], bsp[j + RA * r]);
+    }
     if (j == 0) v[0] = cadd(v[0], a0);
     // inverse FFT_312, radices reversed: stage 1 radix 13 on the registers as they are
     mix::dft_any<RB, true>(v);
@@ -107,17 +141,67 @@ __global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
     __syncthreads();
     // stage 2: radix 24 on z[j + 13 r], twiddle W_312^(-j r), butterflies j < 13; outputs m = j + 13 r go to k2 = g^-m
     if (j < RB) {
+        if constexpr (!TWO) {
 #pragma unroll
-        for (int r = 0; r < RA; ++r) v[r] = lds[(j + RB * r) * W + c];
+            for (int r = 0; r < RA; ++r) v[r] = lds[(j + RB * r) * W + c];
+        }
+        if constexpr (TWO) {
+            // the 24-point butterfly as 8 x 3 by hand (three 8-point butterflies, then eight 3-point ones), its inputs read, twiddled and
+            // consumed eight at a time and its outputs stored three at a time: the 24 inputs, 24 partial results and 24 store addresses are never alive
+            // together (as one dft_any<24> after 24 LDS reads the compiler held all of them: 80 VGPRs + 36 spilled)
+            cf y[RA];
+#pragma unroll
+            for (int n2 = 0; n2 < 3; ++n2) {
+                cf t[8];
+#pragma unroll
+                for (int q1 = 0; q1 < 8; ++q1) {
+                    const int r = 3 * q1 + n2;
+                    t[q1] = lds[(j + RB * r) * W + c];
+                    if (r > 0) {          // times exp(+2 pi i j r / 312), every power from its own sine / cosine: no table of powers alive
+                        unsigned m = j * (unsigned)r;             // < 13 * 23
+                        if (m >= (unsigned)L) m -= L;
+                        t[q1] = cmul(t[q1], cis_frac((float)m * (1.0f / (float)L)));
+                    }
+                }
+                mix::dft_any<8, true>(t);
+#pragma unroll
+                for (int k1 = 0; k1 < 8; ++k1) y[n2 * 8 + k1] = mix::mul_root<RA, true>(t[k1], n2 * k1);
+            }
+            const bool st = (int)col < a.u_cols;
+            const unsigned b = n1 * a.off0u + colb;
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) {
+                cf t[3];
+#pragma unroll
+                for (int n2 = 0; n2 < 3; ++n2) t[n2] = y[n2 * 8 + k1];
+                mix::dft_any<3, true>(t);
+                if (st) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 3; ++k2) stnt(dst + (b + __umul24((unsigned)tout[j + RB * (k1 + 8 * k2)], pu)), t[k2], true);
+                }
+            }
+            if (st && j == 0) *reinterpret_cast<cf*>(dst + b) = y0;
+            return;
+        }
         mix::apply_powers<RA>(v, cis_frac((float)j * (1.0f / (float)L)));
         mix::dft_any<RA, true>(v);
         if ((int)col < a.u_cols) {
             const unsigned b = n1 * a.off0u + colb;
 #pragma unroll
-            for (int r = 0; r < RA; ++r) stnt(dst + (b + tout[j + RB * r]), v[r], a.nt);
+            for (int r = 0; r < RA; ++r) stnt(dst + (b + (unsigned)tout[j + RB * r]), v[r], TWO || a.nt);
             if (j == 0) *reinterpret_cast<cf*>(dst + b) = y0;
         }
     }
+}
+template <int W>
+__global__ __launch_bounds__(pfa::RA * W) void pfa_rader313_kernel(PfaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    rader313_body<W, false>(a, reinterpret_cast<cf*>(smem_raw));
+}
+template <int W>
+__global__ __launch_bounds__(pfa::RA * W) __attribute__((amdgpu_waves_per_eu(6, 6))) void pfa_rader313_two_kernel(PfaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    rader313_body<W, true>(a, reinterpret_cast<cf*>(smem_raw));
 }
 
 // 23-point DFTs over n1 of rows n1*313 + k2 of a.u, in registers; output row k = (c2 k2 + c1 k1) mod 7199
@@ -295,11 +379,21 @@ hipError_t az_pfa_run(const AzPfa* z, bool inv, const cf* src, size_t src_ld, in
     // every image here is 0.76 GB and is next read a whole launch later: nontemporal accesses (2.19 -> 2.13 ms per native frame);
     // SARX_PFA_NT=0 for A/B
     { static const int nt = [] { const char* e = getenv("SARX_PFA_NT"); return e ? atoi(e) : 1; }(); a.nt = nt != 0; }
-    const size_t lds = (size_t)L * W * sizeof(cf) + 2 * L * sizeof(unsigned) + L * sizeof(cf);     // image + the two offset tables + the spectrum of w'
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfa_rader313_kernel<W>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pfa_rader313_kernel<W>, dim3((dst_cols + W - 1) / W, N1), dim3(RA * W), lds, st, a);
+    // two workgroups per CU: 0.45 -> 0.40 ms per launch at 7199 x 13200, the native frame 2.00 -> 1.87 ms (profiles/r03_s_rader_two_ab.log;
+    // SARX_RADER_TWO=0 for A/B)
+    static const int two = [] { const char* e = getenv("SARX_RADER_TWO"); return e ? atoi(e) : 1; }();
+    hipError_t e;
+    if (two && a.nt) {      // the two-workgroup form has the nontemporal accesses compiled in
+        const size_t lds = (size_t)L * W * sizeof(cf) + 2 * L * sizeof(unsigned short);          // image + the two row-number tables: two fit a CU
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfa_rader313_two_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(pfa_rader313_two_kernel<W>, dim3((dst_cols + W - 1) / W, N1), dim3(RA * W), lds, st, a);
+    } else {
+        const size_t lds = (size_t)L * W * sizeof(cf) + 2 * L * sizeof(unsigned) + L * sizeof(cf);     // image + the two offset tables + the spectrum of w'
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfa_rader313_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(pfa_rader313_kernel<W>, dim3((dst_cols + W - 1) / W, N1), dim3(RA * W), lds, st, a);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     dim3 g2((dst_cols + 63) / 64, (P + 3) / 4);
     if (!inv) {

@@ -148,7 +148,19 @@ template <int R, bool INV> __device__ __forceinline__ void dft_any(cf* v) {
     else dft_composite<R, INV>(v);
 }
 
-// v[r] *= w^r, r = 1..R-1, by a multiplication tree of depth ceil(log2 R)
+// v[r] *= w^r, r = 1..R-1, by a multiplication tree of depth ceil(log2 R); the upper half of the tree is consumed as it is
+// produced, so at most R/2 + 1 powers are alive beside the R data registers
+template <int R> __device__ __forceinline__ void apply_powers_progressive(cf* v, cf w1) {
+    constexpr int H = (R + 1) / 2;
+    cf w[H + 1];
+    w[1] = w1;
+#pragma unroll
+    for (int r = 2; r <= H; ++r) w[r] = cmul(w[r / 2], w[r - r / 2]);
+#pragma unroll
+    for (int r = H + 1; r < R; ++r) v[r] = cmul(v[r], cmul(w[r / 2], w[r - r / 2]));
+#pragma unroll
+    for (int r = 1; r <= H; ++r) v[r] = cmul(v[r], w[r]);
+}
 template <int R> __device__ __forceinline__ void apply_powers(cf* v, cf w1) {
     if constexpr (R <= 25) {
         cf w[R];
@@ -158,17 +170,7 @@ template <int R> __device__ __forceinline__ void apply_powers(cf* v, cf w1) {
 #pragma unroll
         for (int r = 1; r < R; ++r) v[r] = cmul(v[r], w[r]);
     } else {
-        // long radices: the upper half of the tree is consumed as it is produced, so at most R/2 + 1 powers are alive
-        // beside the R data registers (the plain form keeps all R and spills under a 128-VGPR cap)
-        constexpr int H = (R + 1) / 2;
-        cf w[H + 1];
-        w[1] = w1;
-#pragma unroll
-        for (int r = 2; r <= H; ++r) w[r] = cmul(w[r / 2], w[r - r / 2]);
-#pragma unroll
-        for (int r = H + 1; r < R; ++r) v[r] = cmul(v[r], cmul(w[r / 2], w[r - r / 2]));
-#pragma unroll
-        for (int r = 1; r <= H; ++r) v[r] = cmul(v[r], w[r]);
+        apply_powers_progressive<R>(v, w1);       // long radices: the plain form keeps all R powers and spills under a 128-VGPR cap
     }
 }
 

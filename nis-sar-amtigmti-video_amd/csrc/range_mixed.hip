@@ -9,12 +9,23 @@
 // (bins t + r N/25) and the spectrum never leaves them.  One HBM round trip of the unpadded line instead of the
 // five padded ones of the chirp-z route (32768-point convolution).
 //
+// Where the fused launch's 0.63 ms at 7199 x 13200 go (ablation builds, MIX_ABL below; profiles/r03_q_range_mixed_ablation.log):
+// without any global load or store 0.54 ms; without the butterflies and twiddles 0.38 ms; with neither - the four LDS crossings,
+// eight barriers and the two phase generators alone - 0.25 ms.  The launch is bound by its own instruction stream and LDS
+// exchanges running in lockstep (ten waves, one workgroup per CU: the 103 KiB image leaves no room for a second line), not by HBM:
+// the copy of the same bytes takes 0.27 ms, and only 0.09 ms of memory time is still exposed beside the arithmetic.
+//
 // Phases: fp64-seeded fixed-point accumulators along each thread's arithmetic progression of bins / samples
 // (phase.hpp); the one bin per thread where the fftfreq sign change falls inside a progression is evaluated directly.
 #include "csa_kernels.h"
 #include "fft_mixed.hpp"
 #include "phase.hpp"
+#include <cstdlib>
+#include <type_traits>
 
+#ifndef MIX_ABL
+#define MIX_ABL 0            // ablation builds only (tools/gpu_r3q.sh): bit 0 no global loads, bit 1 no global stores, bit 2 no butterflies / twiddles - results are wrong
+#endif
 #ifndef MIX_PREFETCH
 #define MIX_PREFETCH 1       // FFT . x . IFFT modes: the next line's first-stage inputs are loaded during this line's inverse half (two bursts)
 #endif
@@ -31,8 +42,10 @@ namespace sarx {
 // The pitches carry a few pad elements (picked with a bank-conflict count of every access: worst case 1.9x the
 // conflict-free LDS cycles on the strided reads of crossing 1, about 3 us of LDS time per 13200-sample line in all).
 // NPF_: how many of the R1 first-stage samples per thread are prefetched for the next line (the rest is loaded at the top of the line)
-template <int N_, int R1_, int R2_, int R3_, int T_, int P1_, int P2_, int P3_, int P4_, int NPF_ = R1_> struct MixCfg {
+// PLANES_: the crossings move re and im separately through a float image (half the bytes: two workgroups per CU), no prefetch
+template <int N_, int R1_, int R2_, int R3_, int T_, int P1_, int P2_, int P3_, int P4_, int NPF_ = R1_, bool PLANES_ = false> struct MixCfg {
     static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_, T = T_, NPF = NPF_;
+    static constexpr bool PLANES = PLANES_;
     static_assert(R1 * R2 * R3 == N, "radices must multiply to the line length");
     static_assert(N / R1 <= T && N / R2 <= T && N / R3 <= T, "one butterfly per thread and stage");
     static constexpr int RMAX = (R1 > R2 ? (R1 > R3 ? R1 : R3) : (R2 > R3 ? R2 : R3));
@@ -41,7 +54,7 @@ template <int N_, int R1_, int R2_, int R3_, int T_, int P1_, int P2_, int P3_, 
     static constexpr int PITCH_F1 = G1 + P1_, PITCH_F2 = G3 + P2_, PITCH_I1 = G3 + P3_, PITCH_I2 = G1 + P4_;
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int LDS_ELEMS = cmax(cmax(R1 * PITCH_F1, R3 * PITCH_F2), cmax(R3 * PITCH_I1, R1 * PITCH_I2));
-    static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * sizeof(cf);
+    static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * (PLANES_ ? sizeof(float) : sizeof(cf));
 };
 
 template <int RA, int PITCH> __device__ __forceinline__ void cross1_write(const cf* v, int j, cf* lds) {
@@ -64,6 +77,35 @@ template <int RC, int PITCH> __device__ __forceinline__ void cross2_read(cf* v, 
 #pragma unroll
     for (int r = 0; r < RC; ++r) v[r] = p[r * PITCH];
 }
+// The same four crossings one component (re, then im) at a time through a float image of half the bytes, so that two lines - two
+// workgroups - are resident on a CU (MixCfg::PLANES): the other workgroup's butterflies run during this one's exchanges and loads.
+// What it buys is the memory time (0.09 ms of 0.63 were exposed beside the arithmetic, none is now: the build without loads and
+// stores runs as long as the real one, profiles/r03_u_range_mixed_planes_ablation.log) - not more arithmetic per second: ten waves
+// sit 3/3/2/2 on the four SIMDs and a second workgroup lands the same way (6/6/4/4), so the two SIMDs with the extra waves bound
+// both forms (3 600 vector instructions per thread-line; starting the second workgroup half a line late, or numbering its threads
+// from another wave so that its part-filled waves sit elsewhere, changed nothing: profiles/r03_v_*).
+template <int COMP> __device__ __forceinline__ float part(const cf& x) { return COMP ? x.y : x.x; }
+template <int COMP> __device__ __forceinline__ void set_part(cf& x, float f) { if (COMP) x.y = f; else x.x = f; }
+template <int RA, int PITCH, int COMP> __device__ __forceinline__ void cross1_write_p(const cf* v, int j, float* lds) {
+    float* p = lds + j;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) p[r * PITCH] = part<COMP>(v[r]);
+}
+template <int RA, int RB, int RC, int PITCH, int COMP> __device__ __forceinline__ void cross1_read_p(cf* v, int j, const float* lds) {
+    const float* p = lds + (j % RA) * PITCH + (j / RA);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) set_part<COMP>(v[r], p[RC * r]);
+}
+template <int RA, int RB, int PITCH, int COMP> __device__ __forceinline__ void cross2_write_p(const cf* v, int j, float* lds) {
+    float* p = lds + (j / RA) * PITCH + (j % RA);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) p[RA * r] = part<COMP>(v[r]);
+}
+template <int RC, int PITCH, int COMP> __device__ __forceinline__ void cross2_read_p(cf* v, int j, const float* lds) {
+    const float* p = lds + j;
+#pragma unroll
+    for (int r = 0; r < RC; ++r) set_part<COMP>(v[r], p[r * PITCH]);
+}
 // butterfly j of a stage with radix R after NS = product of earlier radices: twiddle exp(-+ 2 pi i (j mod NS) r / (NS R))
 template <int R, int NS, bool INV> __device__ __forceinline__ void mix_twiddle(cf* v, int j) {
     if constexpr (NS > 1) {
@@ -75,10 +117,11 @@ template <int R, int NS, bool INV> __device__ __forceinline__ void mix_twiddle(c
 }
 
 template <class C, int MODE>
-__global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
+__device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_raw) {
     constexpr int N = C::N, R1 = C::R1, R2 = C::R2, R3 = C::R3, G1 = C::G1, G2 = C::G2, G3 = C::G3;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool PL = C::PLANES;
     cf* lds = reinterpret_cast<cf*>(smem_raw);
+    float* ldsf = reinterpret_cast<float*>(smem_raw);
     constexpr bool FWD = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED || MODE == RG_CONV);
     constexpr bool BWD = (MODE == RG_IFFT || MODE == RG_IFFT_PHI3 || MODE == RG_FUSED || MODE == RG_CONV);
     // Phi_2 along a thread's bins k = t + r G3: non-negative frequencies for r <= R_LO and negative ones for r >= R_HI
@@ -90,13 +133,14 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
     // pipe idles through the whole transform.  The next line's R1 first-stage samples per thread wait in registers instead,
     // requested in two bursts during the inverse half (after the mid-line vector loads of RG_CONV's filter spectrum: vmcnt
     // retires in order, a load issued behind the prefetch would wait for all of it).
-    constexpr bool PRE = MIX_PREFETCH && FWD && BWD;
+    constexpr bool PRE = MIX_PREFETCH && FWD && BWD && !PL;
     const size_t in_ld = (MODE == RG_CONV) ? a.conv_in_ld : (size_t)N;
     auto load_first_stage = [&](cf* dstv, const cf* p, int t, int r0, int r1) {
 #pragma unroll
         for (int r = 0; r < R1; ++r)
             if (r >= r0 && r < r1) {
-                if constexpr (MODE == RG_CONV) dstv[r] = (t + r * G1 < a.conv_valid) ? ld8<false>(p + t + r * G1) : make_float2(0.f, 0.f);
+                if constexpr ((MIX_ABL & 1) != 0) dstv[r] = make_float2((float)t * 1e-3f + (float)r, 1.f + (float)(size_t)p * 1e-20f);
+                else if constexpr (MODE == RG_CONV) dstv[r] = (t + r * G1 < a.conv_valid) ? ld8<false>(p + t + r * G1) : make_float2(0.f, 0.f);
                 else dstv[r] = ld8<false>(p + t + r * G1);
             }
     };
@@ -107,6 +151,25 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
             load_first_stage(nxt, a.in + (size_t)range_row(a, blockIdx.x) * in_ld, threadIdx.x, 0, NPF);
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the loop header's merged wait state is then the back edge's (stores stay in flight)
     }
+    // one crossing: write, barrier, read - or, component by component, write re, barrier, read re, barrier, write im, barrier, read im
+    // (the reader's registers take the new re while the old im still waits to be written: no more registers than one line share)
+    auto cross = [&](int t, int gw, int gr, auto wr, auto rd, auto between) {
+        if constexpr (!PL) {
+            if (t < gw) wr(std::integral_constant<int, -1>{});
+            between();
+            __syncthreads();
+            if (t < gr) rd(std::integral_constant<int, -1>{});
+        } else {
+            if (t < gw) wr(std::integral_constant<int, 0>{});
+            __syncthreads();
+            if (t < gr) rd(std::integral_constant<int, 0>{});
+            __syncthreads();
+            if (t < gw) wr(std::integral_constant<int, 1>{});
+            __syncthreads();
+            if (t < gr) rd(std::integral_constant<int, 1>{});
+        }
+    };
+    auto nothing = [] {};
     for (int line = blockIdx.x; line < a.n_az; line += gridDim.x) {
         const int row = range_row(a, line);
         int t = threadIdx.x;
@@ -131,24 +194,30 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
                 } else {
                     load_first_stage(v, src, t, 0, R1);      // RG_CONV: the line is shorter than the transform, zeros beyond it are never read
                 }
-                mix::dft_any<R1, false>(v);
-                cross1_write<R1, C::PITCH_F1>(v, t, lds);
+                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R1, false>(v);
             }
-            __syncthreads();
+            cross(t, G1, G2,
+                  [&](auto cc) { constexpr int CC = decltype(cc)::value;
+                                 if constexpr (CC < 0) cross1_write<R1, C::PITCH_F1>(v, t, lds); else cross1_write_p<R1, C::PITCH_F1, CC>(v, t, ldsf); },
+                  [&](auto cc) { constexpr int CC = decltype(cc)::value;
+                                 if constexpr (CC < 0) cross1_read<R1, R2, R3, C::PITCH_F1>(v, t, lds); else cross1_read_p<R1, R2, R3, C::PITCH_F1, CC>(v, t, ldsf); },
+                  nothing);
             // stage 2: radix R2, NS = R1
             if (t < G2) {
-                cross1_read<R1, R2, R3, C::PITCH_F1>(v, t, lds);
-                mix_twiddle<R2, R1, false>(v, t);
-                mix::dft_any<R2, false>(v);
+                if constexpr ((MIX_ABL & 4) == 0) mix_twiddle<R2, R1, false>(v, t);
+                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R2, false>(v);
             }
-            __syncthreads();
-            if (t < G2) cross2_write<R1, R2, C::PITCH_F2>(v, t, lds);
-            __syncthreads();
+            __syncthreads();                            // every read of the image is finished
+            cross(t, G2, G3,
+                  [&](auto cc) { constexpr int CC = decltype(cc)::value;
+                                 if constexpr (CC < 0) cross2_write<R1, R2, C::PITCH_F2>(v, t, lds); else cross2_write_p<R1, R2, C::PITCH_F2, CC>(v, t, ldsf); },
+                  [&](auto cc) { constexpr int CC = decltype(cc)::value;
+                                 if constexpr (CC < 0) cross2_read<R3, C::PITCH_F2>(v, t, lds); else cross2_read_p<R3, C::PITCH_F2, CC>(v, t, ldsf); },
+                  nothing);
             // stage 3: radix R3, NS = R1 R2; thread t ends with bins k = t + r G3
             if (t < G3) {
-                cross2_read<R3, C::PITCH_F2>(v, t, lds);
-                mix_twiddle<R3, R1 * R2, false>(v, t);
-                mix::dft_any<R3, false>(v);
+                if constexpr ((MIX_ABL & 4) == 0) mix_twiddle<R3, R1 * R2, false>(v, t);
+                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R3, false>(v);
                 if constexpr (MODE == RG_CONV) {      // times the filter spectrum, bins k = t + r G3 (the inverse starts from these registers)
                     const cf* __restrict__ mv = a.mulvec;
 #pragma unroll
@@ -185,27 +254,31 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
 #pragma unroll
                     for (int r = 0; r < R3; ++r) v[r] = src[t + r * G3];
                 }
-                mix::dft_any<R3, true>(v);
+                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R3, true>(v);
             }
             if constexpr (FWD) __syncthreads();         // forward stage 3's reads of the image are finished
-            if (t < G3) cross1_write<R3, C::PITCH_I1>(v, t, lds);
-            if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, 0, NPF / 2); }
-            __syncthreads();
+            cross(t, G3, G2,
+                  [&](auto cc) { constexpr int CC = decltype(cc)::value;
+                                 if constexpr (CC < 0) cross1_write<R3, C::PITCH_I1>(v, t, lds); else cross1_write_p<R3, C::PITCH_I1, CC>(v, t, ldsf); },
+                  [&](auto cc) { constexpr int CC = decltype(cc)::value;
+                                 if constexpr (CC < 0) cross1_read<R3, R2, R1, C::PITCH_I1>(v, t, lds); else cross1_read_p<R3, R2, R1, C::PITCH_I1, CC>(v, t, ldsf); },
+                  [&] { if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, 0, NPF / 2); } });
             // stage 2: radix R2, NS = R3
             if (t < G2) {
-                cross1_read<R3, R2, R1, C::PITCH_I1>(v, t, lds);
-                mix_twiddle<R2, R3, true>(v, t);
-                mix::dft_any<R2, true>(v);
+                if constexpr ((MIX_ABL & 4) == 0) mix_twiddle<R2, R3, true>(v, t);
+                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R2, true>(v);
             }
             __syncthreads();
-            if (t < G2) cross2_write<R3, R2, C::PITCH_I2>(v, t, lds);
-            if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, NPF / 2, NPF); }
-            __syncthreads();
+            cross(t, G2, G1,
+                  [&](auto cc) { constexpr int CC = decltype(cc)::value;
+                                 if constexpr (CC < 0) cross2_write<R3, R2, C::PITCH_I2>(v, t, lds); else cross2_write_p<R3, R2, C::PITCH_I2, CC>(v, t, ldsf); },
+                  [&](auto cc) { constexpr int CC = decltype(cc)::value;
+                                 if constexpr (CC < 0) cross2_read<R1, C::PITCH_I2>(v, t, lds); else cross2_read_p<R1, C::PITCH_I2, CC>(v, t, ldsf); },
+                  [&] { if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, NPF / 2, NPF); } });
             // stage 3: radix R1, NS = R3 R2; thread t ends with samples n = t + r G1
             if (t < G1) {
-                cross2_read<R1, C::PITCH_I2>(v, t, lds);
-                mix_twiddle<R1, R3 * R2, true>(v, t);
-                mix::dft_any<R1, true>(v);
+                if constexpr ((MIX_ABL & 4) == 0) mix_twiddle<R1, R3 * R2, true>(v, t);
+                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R1, true>(v);
                 const float s = a.inv_n;
                 if constexpr (MODE == RG_CONV) {      // only the cropped window is written
 #pragma unroll
@@ -222,7 +295,8 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
                     for (int r = 0; r < R1; ++r) {
                         cf ph = q.next();
                         ph.x *= s; ph.y *= s;
-                        st8<false>(dst + t + r * G1, cmul(v[r], ph));
+                        const cf y = cmul(v[r], ph);
+                        if ((MIX_ABL & 2) == 0 || y.x == 12345.678f) st8<false>(dst + t + r * G1, y);
                     }
                 }
             }
@@ -230,8 +304,22 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
     }
 }
 
+template <class C, int MODE>
+__global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    range_mixed_body<C, MODE>(a, smem_raw);
+}
+// two workgroups per CU (MixCfg::PLANES): ten or twelve waves each, so a SIMD can be asked for six: 80 VGPRs
+template <class C, int MODE>
+__global__ __launch_bounds__(C::T) __attribute__((amdgpu_waves_per_eu(6, 6))) void range_mixed_planes_kernel(RangeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    range_mixed_body<C, MODE>(a, smem_raw);
+}
+
 // ---- supported lengths ----------------------------------------------------------------------------------------------
 using Mix13200 = MixCfg<13200, 24, 22, 25, 640, 0, 8, 1, 3>;   // pads from the bank-conflict count of tools/lds_layout_sim.py
+// the same radices, re / im planes through a 54 KiB float image: two workgroups per CU (pads: tools/lds_layout_sim.py 13200 24 22 25 640 f32)
+using Mix13200P = MixCfg<13200, 24, 22, 25, 640, 0, 8, 25, 19, 24, true>;
 // 19683 = 27^3: the circular length for the 'same' convolution of a 13200-sample line with the reference's 12001-tap
 // matched filter (sar_satellite_sim.py:377-392).  Any length >= 19200 holds it - the wrapped ends of the 25200-sample full
 // convolution then fall on the 6000 samples either side of the window that 'same' discards - and of the lengths whose
@@ -241,10 +329,12 @@ using Mix13200 = MixCfg<13200, 24, 22, 25, 640, 0, 8, 1, 3>;   // pads from the 
 using Mix19683 = MixCfg<19683, 27, 27, 27, 768, 0, 2, 0, 2, 19>;     // 19 of the 27 rows prefetched: every row a 13200-sample line has samples in (27 rows spill at 168 VGPRs)
 
 template <class C, int MODE> static hipError_t launch_mixed(const RangeArgs& a, int cus, hipStream_t st) {
-    auto k = range_mixed_kernel<C, MODE>;
+    void (*k)(RangeArgs);
+    if constexpr (C::PLANES) k = range_mixed_planes_kernel<C, MODE>; else k = range_mixed_kernel<C, MODE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return e;
-    const int per_cu = (int)((160 * 1024) / C::LDS_BYTES) < 1 ? 1 : (int)((160 * 1024) / C::LDS_BYTES);
+    int per_cu = (int)((160 * 1024) / C::LDS_BYTES) < 1 ? 1 : (int)((160 * 1024) / C::LDS_BYTES);
+    if (C::PLANES && per_cu > 2) per_cu = 2;            // 80 VGPRs: six waves per SIMD
     const int grid = persistent_grid(per_cu, cus, a.n_az);
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::T), C::LDS_BYTES, st, a);
     return hipGetLastError();
@@ -274,7 +364,12 @@ hipError_t launch_range_conv(int m, const RangeArgs& a, int cus, hipStream_t st)
 
 hipError_t launch_range_mixed(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st) {
     switch (n_rg) {
-        case 13200: return launch_mixed_mode<Mix13200>(mode, a, cus, st);
+        case 13200: {
+            // fused launch at 7199 x 13200: 0.635 -> 0.595 ms with two workgroups per CU (profiles/r03_v_range_mixed_planes.log; SARX_MIXED_PLANES=0 for A/B)
+            static const int planes = [] { const char* e = getenv("SARX_MIXED_PLANES"); return e ? atoi(e) : 1; }();
+            if (planes && mode == RG_FUSED) return launch_mixed<Mix13200P, RG_FUSED>(a, cus, st);
+            return launch_mixed_mode<Mix13200>(mode, a, cus, st);
+        }
     }
     return hipErrorInvalidValue;
 }
