@@ -3,7 +3,7 @@ fixture and the oracle, including the reference's native extents 7199 (azimuth) 
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import ROOT, load_golden
 from oracle import csa_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -229,3 +229,44 @@ def test_prime_factor_route_equals_chirp_z_route(monkeypatch):
         buf.release()
     pfa.close()
     czt.close()
+
+
+def test_one_workgroup_forms_kept_for_ab_still_match(tmp_path):
+    """SARX_RADER_TWO=0 / SARX_MIXED_PLANES=0 select the one-workgroup-per-CU forms of the Rader and the 13200-sample fused range
+    launches (the A/B partners of DESIGN.md 4.6).  The switches are read once per process, so a child process focuses the same
+    seeded native-size echo with them and the two images are compared (different twiddle arithmetic: not bit-identical)."""
+    import os
+    import subprocess
+    import sys
+    import sarx
+    from sarx import radar
+    n_az, n_rg = 7199, 13200
+    out = tmp_path / "old_forms.npy"
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'nis-sar-amtigmti-video_amd')!r})\n"
+        "import sarx\n"
+        "from sarx import radar, _ffi\n"
+        f"n_az, n_rg = {n_az}, {n_rg}\n"
+        "ctx = sarx.Context(0)\n"
+        "plan = sarx.CsaPlan(ctx, n_az, n_rg, *radar.focus_args(), flags=_ffi.FUSE_RANGE)\n"
+        "d_in, d_out = ctx.alloc(n_az * n_rg * 8), ctx.alloc(n_az * n_rg * 8)\n"
+        "ctx.fill_noise(d_in, n_az * n_rg, 4242)\n"
+        "plan.focus_dev(d_in, d_out)\n"
+        f"np.save({str(out)!r}, d_out.download(np.complex64, (n_az, n_rg))[::37])\n"
+    )
+    env = dict(os.environ, SARX_RADER_TWO="0", SARX_MIXED_PLANES="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    old = np.load(out)
+    from sarx import _ffi
+    ctx = sarx.default_context()
+    plan = sarx.CsaPlan(ctx, n_az, n_rg, *radar.focus_args(), flags=_ffi.FUSE_RANGE)
+    d_in, d_out = ctx.alloc(n_az * n_rg * 8), ctx.alloc(n_az * n_rg * 8)
+    ctx.fill_noise(d_in, n_az * n_rg, 4242)
+    plan.focus_dev(d_in, d_out)
+    new = d_out.download(np.complex64, (n_az, n_rg))[::37]
+    assert np.isfinite(new).all() and np.abs(new).max() > 0
+    assert orc.rel_l2(new, old) < 2e-6
+    for b in (d_in, d_out):
+        b.release()
+    plan.close()
