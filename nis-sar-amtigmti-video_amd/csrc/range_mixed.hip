@@ -179,6 +179,10 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
         const int next_line = line + gridDim.x;
         const cf* nsrc = a.in + (size_t)range_row(a, next_line < a.n_az ? next_line : line) * in_ld;   // the last line re-reads itself (never used)
         cf v[C::RMAX];
+        // under the 80-VGPR cap of the two-workgroup form the compiler hoisted the phase seeds' line-invariant fp64 products out of the
+        // line loop and then spilled them (+7.5 % HBM traffic from scratch): opaque per-line copies of df / dt keep them inside
+        double df = a.df, dt = a.dt;
+        if constexpr (PL) asm volatile("" : "+s"(df), "+s"(dt));
         if (line != (int)blockIdx.x) __syncthreads();   // the previous line's last reads of the image are finished
         // the row's phase constants through the scalar cache (as vector loads next to their use their latency was exposed per line)
         double2 c2 = make_double2(0, 0), c3 = c2;
@@ -232,15 +236,15 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                         for (int r = 0; r < R3; ++r) dst[t + r * G3] = v[r];
                     }
                 } else {
-                    FixPhase lo = phi2_seed(t, G3, c2, a.df);                        // numpy.fft.fftfreq order: k, then k - N
-                    FixPhase hi = phi2_seed(t + R_HI * G3 - N, G3, c2, a.df);
+                    FixPhase lo = phi2_seed(t, G3, c2, df);                        // numpy.fft.fftfreq order: k, then k - N
+                    FixPhase hi = phi2_seed(t + R_HI * G3 - N, G3, c2, df);
 #pragma unroll
                     for (int r = 0; r < R3; ++r) {
                         const int k = t + r * G3;
                         cf ph;
                         if (r <= R_LO) ph = lo.next();
                         else if (r >= R_HI) ph = hi.next();
-                        else ph = phi2_at(k < HALF ? k : k - N, c2, a.df);
+                        else ph = phi2_at(k < HALF ? k : k - N, c2, df);
                         v[r] = cmul(v[r], ph);
                         if constexpr (MODE == RG_FFT_PHI2) dst[k] = v[r];
                     }
@@ -290,7 +294,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
 #pragma unroll
                     for (int r = 0; r < R1; ++r) dst[t + r * G1] = make_float2(v[r].x * s, v[r].y * s);
                 } else {
-                    FixPhase q = phi3_seed(t, G1, c3, a.dt, a.t_start, a.t0);
+                    FixPhase q = phi3_seed(t, G1, c3, dt, a.t_start, a.t0);
 #pragma unroll
                     for (int r = 0; r < R1; ++r) {
                         cf ph = q.next();
