@@ -46,6 +46,8 @@ def parse_args(argv=None):
     ap.add_argument("--unfused", action="store_true", help="run range passes 2 and 3 as two launches")
     ap.add_argument("--passes", action="store_true", help="also print every pass alone to stderr")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-sample", action="store_true",
+                    help="cpu_baseline on an 8192^2 sample scaled by sample count (~8 s) instead of the real frame on one thread (~30 s at 16384^2)")
     ap.add_argument("--no-batch", action="store_true", help="skip the batch64 block (BASELINE config 5)")
     ap.add_argument("--batch-frames", type=int, default=64)
     ap.add_argument("--batch-size", type=int, default=8192)
@@ -230,6 +232,9 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
 
 
 def main():
+    # rank start, before `import sarx` / any GPU call, whoever launched this rank (our own spawn_ranks or a bare
+    # `python -m torch.distributed.run ... bench.py`): RCCL across processes needs dmabuf IPC on this pool
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     argv = sys.argv[1:]
     a = parse_args(argv)
     env_world = os.environ.get("WORLD_SIZE")
@@ -492,11 +497,18 @@ def main():
     if rank == 0 and world == 1 and a.config3:
         line["config3_two_channel"] = run_config3(sarx, ctx, a.batch_size, cpu=not a.no_cpu)
     if rank == 0:
-        if world == 1 and not a.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(n)
-            mt = min(os.cpu_count() or 1, 32)
-            if mt > 1:                              # the all-core figure on the real frame next to the reference-style single thread
-                line["cpu_baseline_threads"] = cpu_baseline(n, workers=mt, scaled=False)
+        if not a.no_cpu:
+            if world == 1:
+                # one thread (how the reference's NumPy runs) on the REAL frame, row-blocked lean path: ~30 s at 16384^2
+                line["cpu_baseline"] = cpu_baseline(n, workers=1, scaled=a.cpu_sample)
+                mt = min(os.cpu_count() or 1, 32)
+                if mt > 1:                          # the all-core figure on the real frame next to the reference-style single thread
+                    line["cpu_baseline_threads"] = cpu_baseline(n, workers=mt, scaled=False)
+            else:
+                # N > 1 lines carry it too (north_star: every N next to the NumPy CPU path): rank 0's host cores, one thread, the bounded
+                # sample, timed AFTER every GPU leg while the other ranks wait at the final barrier - it is not part of any timed region
+                line["cpu_baseline"] = cpu_baseline(n, workers=1, scaled=True)
+                line["cpu_baseline"]["sample"] += f"; timed on rank 0 of {world} after the GPU legs, the other ranks idle at the barrier"
         emit(line)
     if dist is not None:
         dist.barrier()

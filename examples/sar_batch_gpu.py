@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # rank start, before `import sarx` / any GPU call (dmabuf IPC for RCCL)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -63,7 +65,7 @@ def main():
     for h in a.headings:
         for algo, focus_tgt in (("mBP", True), ("StdBP", False)):     # :283-286
             run_id = f"{v['name']}_{int(v['speed'])}_{int(h)}_{algo}"
-            state = {"d_raw": None, "n_sp": 0}
+            state = {"d_raw": None, "n_sp": 0, "local_max": 0.0}
             t0 = time.time()
 
             def process_frame(f):
@@ -80,7 +82,9 @@ def main():
                 vf = v_tgt if focus_tgt else np.zeros(3)
                 img = sarx.tdbp_gpu(d_raw, p_cpi, v_cpi, t_st, n_sp, vel_focus=vf, t_pulses=t_cpi,
                                     scene_size=v["swath"], nx=a.nx, ny=a.nx, consts=k, ctx=ctx)   # :318-321
-                return img.astype(np.complex64).view(np.float32)                               # stack slot [ny x 2 nx]
+                img = img.astype(np.complex64)
+                state["local_max"] = max(state["local_max"], float(np.abs(img).max()))         # this rank's share of g_max (:337)
+                return img.view(np.float32)                                                    # stack slot [ny x 2 nx]
 
             comm = TorchStackComm() if world > 1 else LocalStackComm()
             stack = np.ascontiguousarray(run_batch_host(frame_ids, world, rank, process_frame, comm,
@@ -88,11 +92,13 @@ def main():
             if state["d_raw"] is not None:
                 state["d_raw"].release()
             ctx.sync()
+            # g_max = max over ALL frames of max|frame| (:337-338): each rank has reduced the frames it focused, one float is
+            # all-reduced with max (every rank takes part) - nobody scans the gathered stack for it
+            g_max = comm.all_reduce_max(state["local_max"]) or 1.0
             dt = time.time() - t0
             if rank != 0:
                 continue
             frames, n_sp, t_cpi = stack, state["n_sp"], t_vec_all[:CPI_PULSES]
-            g_max = float(np.abs(stack).max()) or 1.0                 # :336-337
             out = os.path.join(a.outdir, run_id + ".npz")
             np.savez(out, frames=stack, g_max=g_max, extent=np.array([-v["swath"] / 2, v["swath"] / 2] * 2), fps=FPS)
             print(f"{run_id}: {len(frames)} frames of {len(t_cpi)} pulses x {n_sp} samples -> {a.nx}x{a.nx} in {dt:.2f} s "

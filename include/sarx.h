@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 203   /* 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
+#define SARX_VERSION 204   /* 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -93,6 +93,13 @@ int sarx_persistent_grid(int wgs_per_cu, int cus, int work_items);
 /* ---- device memory and timing (so the Python host needs no torch) -------- */
 int sarx_malloc(sarx_ctx* ctx, size_t bytes, void** out_dptr);
 int sarx_free(sarx_ctx* ctx, void* dptr);
+/* Page-locked host memory for the results (or inputs) of the *_host entry points and sarx_memcpy_*: such a buffer is copied
+ * with one DMA at the PCIe rate - no staging through pinned chunks, no first touch of fresh pages (a new 2 GiB NumPy result
+ * array costs ~90 ms of page faults at 16384^2).  Allocation itself is slow (~0.25 s per GiB): allocate once, reuse.  The
+ * Python facade keeps a small pool of these for the arrays sar_focus_csa returns (the reference allocates its result per
+ * call, sar_ati_dcpa_sim_csa.py:385-396; callee-allocates stays the contract). */
+int sarx_host_alloc(sarx_ctx* ctx, size_t bytes, void** out_hptr);
+int sarx_host_free(sarx_ctx* ctx, void* hptr);
 int sarx_memcpy_h2d(sarx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int sarx_memcpy_d2h(sarx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int sarx_memcpy_d2d(sarx_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
@@ -221,6 +228,9 @@ int sarx_mask_phase_frac_dev(sarx_ctx* ctx, const float* d_phase, const float* d
                              float* d_out);
 /* out[i] = |in[i]|, complex64 in, fp32 out (sar_ati_dcpa_sim_csa.py:416 on its own: full-resolution stack slot) */
 int sarx_magnitude_dev(sarx_ctx* ctx, const void* d_in, float* d_out, size_t n);
+/* *d_max = max(*d_max, max_i |d_x[i]|) over an fp32 device buffer (clear *d_max with sarx_memset first): a rank's share of
+ * g_max = max([np.max(np.abs(fr)) for fr in loaded_frames]) (sar_batch_sim.py:337); asynchronous on the ctx stream */
+int sarx_max_abs_f32_dev(sarx_ctx* ctx, const float* d_x, size_t n, float* d_max);
 /* ati_phase[~(mag > thr)] = 0  (sar_ati_dcpa_sim_csa.py:447-449); d_out may alias d_phase */
 int sarx_mask_phase_dev(sarx_ctx* ctx, const float* d_phase, const float* d_mag, size_t n, float threshold,
                         float* d_out);
@@ -315,6 +325,10 @@ int sarx_comm_init(sarx_ctx* ctx, const void* id, int n_ranks, int rank);
 /* recv[rank r] = send of rank r; bytes_per_rank multiple of 4; async on the ctx comm stream,
  * ordered after everything already enqueued on the compute stream */
 int sarx_allgather_dev(sarx_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* d_buf[i] = max over ranks of d_buf[i] (fp32, in place); same stream ordering as the gather.  The collective half of the
+ * global display normalisation of a frame stack, g_max = max over all frames of max|frame| (sar_batch_sim.py:337-338):
+ * every rank reduces its own frames with sarx_max_abs_f32_dev, one float per rank crosses xGMI. */
+int sarx_allreduce_max_dev(sarx_ctx* ctx, float* d_buf, size_t count);
 int sarx_comm_sync(sarx_ctx* ctx);
 /* device-side only: later work on the compute stream waits for every gather enqueued so far
  * (call before overwriting a send buffer that an earlier sarx_allgather_dev may still read) */

@@ -262,6 +262,28 @@ hipError_t launch_magnitude(const cf* in, float* out, size_t n, hipStream_t st) 
     return hipGetLastError();
 }
 
+// max |x| of an fp32 buffer folded into *out (non-negative floats order like their bit patterns, so one atomicMax on the
+// bits per wave): the per-rank half of the global display normalisation of a frame stack (sar_batch_sim.py:337-338)
+__global__ __launch_bounds__(256) void max_abs_f32_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+hipError_t launch_max_abs_f32(const float* x, size_t n, float* out, hipStream_t st) {
+    size_t b = (n / 4 + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(max_abs_f32_kernel, dim3((unsigned)b), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(out));
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------
 // corner turn: out[c][r] = in[r][c].  64x64 complex64 tiles staged through a
 // padded LDS image; both the read and the write are 512-byte row segments.

@@ -31,6 +31,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
@@ -71,10 +72,11 @@ static bool load_rccl(std::string& err) {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
     g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(h, "ncclGetVersion");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
         err = "librccl lacks a required symbol";
         dlclose(h);
         return false;
@@ -90,6 +92,10 @@ struct sarx_ctx {
     int cus = 256;                     // compute units of this device (persistent grids are sized from it)
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;
+    static constexpr int SLAB_STREAMS = 8;
+    hipStream_t slab_stream[SLAB_STREAMS] = {};   // slab mode with SARX_SLAB_STREAMS > 1: independent tile groups on concurrent streams
+    hipEvent_t slab_ev[SLAB_STREAMS] = {};
+    hipEvent_t slab_fork = nullptr;
     hipEvent_t ev[N_EVENTS] = {};
     bool ev_set[N_EVENTS] = {};
     hipEvent_t comm_fence = nullptr;
@@ -131,6 +137,7 @@ struct sarx_plan {
     float* max_slot = nullptr;         // sarx_csa_plan_set_max_slot: device float that receives max |image| of every focus
     bool az_nt = false;    // azimuth tile launches use nontemporal accesses (images >= 512 MiB; SARX_AZ_NT=0/1 overrides)
     int slab_tiles = 0;    // > 0: slab mode of sarx_csa_focus_dev with this many azimuth tiles per group (SARX_SLAB_MIB)
+    int slab_streams = 1;  // SARX_SLAB_STREAMS: the groups' three-launch chains round-robin over this many streams
     double2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr;
     float2* buf_b = nullptr;           // scratch image
     float2* buf_a = nullptr;           // second scratch (RG_MAJOR only)
@@ -164,6 +171,17 @@ static int fail(sarx_ctx* c, int code, const char* fmt, ...) {
 static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, bool narrow = false) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return e;
+    if (!narrow && bytes >= 4 * sarx_ctx::COPY_CHUNK) {
+        // a buffer from sarx_host_alloc (page-locked, already faulted in) needs no staging: one DMA at the PCIe rate, no host memcpy,
+        // no first touch.  A pointer the runtime does not know is ordinary pageable memory (the query fails for it: clear that error).
+        hipPointerAttribute_t at{};
+        const void* host = to_device ? src : dst;
+        if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost) {
+            e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, c->stream);
+            return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+        }
+        (void)hipGetLastError();
+    }
     if (bytes < 4 * sarx_ctx::COPY_CHUNK && !narrow) {
         e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, c->stream);
         return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
@@ -186,7 +204,7 @@ static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t by
     }
     hipError_t errs[T];
     for (int i = 0; i < T; ++i) errs[i] = hipSuccess;
-    std::vector<std::thread> th;
+    std::thread th[T];                 // fixed storage: nothing here allocates, so nothing but thread creation can throw
     // thread i copies chunks i, i + T, ...; if a thread cannot be started (std::system_error must not cross the C ABI) the
     // calling thread does that share itself after the others
     auto share = [=, &errs](int i) {
@@ -215,13 +233,13 @@ static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t by
             if (r == hipSuccess) r = hipStreamSynchronize(c->copy_stream[i]);
             errs[i] = r;
         };
-    std::vector<int> inline_shares;
+    bool inline_share[T] = {};
     for (int i = 0; i < T; ++i) {
-        try { th.emplace_back(share, i); }
-        catch (const std::system_error&) { inline_shares.push_back(i); }
+        try { th[i] = std::thread(share, i); }
+        catch (...) { inline_share[i] = true; }          // std::system_error / std::bad_alloc: no exception crosses the C ABI
     }
-    for (int i : inline_shares) share(i);
-    for (auto& t : th) t.join();
+    for (int i = 0; i < T; ++i) if (inline_share[i]) share(i);
+    for (int i = 0; i < T; ++i) if (th[i].joinable()) th[i].join();     // every started thread is joined on the one exit path
     for (int i = 0; i < T; ++i)
         if (errs[i] != hipSuccess) return errs[i];
     return hipSuccess;
@@ -300,6 +318,11 @@ int sarx_destroy(sarx_ctx* c) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
         if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
     }
+    for (int k = 0; k < sarx_ctx::SLAB_STREAMS; ++k) {
+        if (c->slab_stream[k]) hipStreamDestroy(c->slab_stream[k]);
+        if (c->slab_ev[k]) hipEventDestroy(c->slab_ev[k]);
+    }
+    if (c->slab_fork) hipEventDestroy(c->slab_fork);
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->comm_stream);
     delete c;
@@ -331,6 +354,15 @@ int sarx_malloc(sarx_ctx* c, size_t bytes, void** out) {
     return SARX_OK;
 }
 int sarx_free(sarx_ctx* c, void* p) { NEED_CTX(c); HIPCHK(c, hipFree(p)); return SARX_OK; }
+int sarx_host_alloc(sarx_ctx* c, size_t bytes, void** out) {
+    NEED_CTX(c);
+    if (!out) return fail(c, SARX_ERR_INVALID, "out_hptr is NULL");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return SARX_OK;
+}
+int sarx_host_free(sarx_ctx* c, void* p) { NEED_CTX(c); if (p) HIPCHK(c, hipHostFree(p)); return SARX_OK; }
 int sarx_memcpy_h2d(sarx_ctx* c, void* d, const void* s, size_t n) {
     NEED_CTX(c);
     HIPCHK(c, staged_copy(c, d, s, n, true));
@@ -424,6 +456,10 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
             if (q < 1) q = 1;
             if (q > n_az / p->az_s) q = n_az / p->az_s;
             p->slab_tiles = q;
+        }
+        if (const char* e3 = getenv("SARX_SLAB_STREAMS")) {
+            const int k = atoi(e3);
+            if (k >= 1 && k <= sarx_ctx::SLAB_STREAMS) p->slab_streams = k;
         }
     }
     if (const char* e = getenv("SARX_AZ_W")) { const int w = atoi(e); if ((w == 16 || w == 32 || w == 64) && n_rg % w == 0) p->az_w = w; }
@@ -781,8 +817,23 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
         float2* last = rg_major ? p->buf_a : (float2*)d_image;
         if ((rc = az_step(p, false, false, S, d_phist, d_image, 0, S)) != SARX_OK) return rc;       // forward step A, whole image
         bool marked = false;
-        for (int q0 = 0; q0 < RA; q0 += Q) {
+        // The groups are independent of each other between the two whole-image launches, so their chains may run on several
+        // streams at once: a group's 128-line range launch leaves half the CUs to the neighbouring groups' tile launches.
+        const int NS = p->slab_streams;
+        struct StreamGuard { sarx_ctx* c; hipStream_t main; ~StreamGuard() { c->stream = main; } } guard{c, c->stream};
+        if (NS > 1) {
+            if (!c->slab_fork) HIPCHK(c, hipEventCreateWithFlags(&c->slab_fork, hipEventDisableTiming));
+            for (int k = 0; k < NS; ++k) {
+                if (!c->slab_stream[k]) HIPCHK(c, hipStreamCreateWithFlags(&c->slab_stream[k], hipStreamNonBlocking));
+                if (!c->slab_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->slab_ev[k], hipEventDisableTiming));
+            }
+            HIPCHK(c, hipEventRecord(c->slab_fork, guard.main));
+            for (int k = 0; k < NS; ++k) HIPCHK(c, hipStreamWaitEvent(c->slab_stream[k], c->slab_fork, 0));
+        }
+        int gi = 0;
+        for (int q0 = 0; q0 < RA; q0 += Q, ++gi) {
             const int nq = (q0 + Q <= RA) ? Q : RA - q0;
+            if (NS > 1) c->stream = c->slab_stream[gi % NS];
             if ((rc = az_step(p, false, true, S, d_image, p->buf_b, q0, nq)) != SARX_OK) return rc;
             RangeArgs a = range_args(p, p->buf_b, p->buf_b);
             a.n_az = nq * S; a.row0 = q0; a.row_inner = nq; a.row_stride = RA;
@@ -792,6 +843,12 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
             if (mark && p->mark_stop >= 0) { HIPCHK(c, hipEventRecord(c->ev[p->mark_stop], c->stream)); c->ev_set[p->mark_stop] = true; marked = true; }
             if ((rc = az_step(p, true, false, RA, p->buf_b, p->buf_b, q0, nq)) != SARX_OK) return rc;   // inverse step A, stride RA
         }
+        c->stream = guard.main;
+        if (NS > 1)
+            for (int k = 0; k < NS; ++k) {
+                HIPCHK(c, hipEventRecord(c->slab_ev[k], c->slab_stream[k]));
+                HIPCHK(c, hipStreamWaitEvent(guard.main, c->slab_ev[k], 0));
+            }
         if ((rc = az_step(p, true, true, RA, p->buf_b, last, 0, S)) != SARX_OK) return rc;           // inverse step B, whole image
         if ((rc = look_finish(p)) != SARX_OK) return rc;
         if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
@@ -995,6 +1052,13 @@ int sarx_magnitude_dev(sarx_ctx* c, const void* in, float* out, size_t n) {
     NEED_CTX(c);
     if (!in || !out) return fail(c, SARX_ERR_INVALID, "NULL pointer");
     if (n) HIPCHK(c, launch_magnitude((const float2*)in, out, n, c->stream));
+    return SARX_OK;
+}
+
+int sarx_max_abs_f32_dev(sarx_ctx* c, const float* x, size_t n, float* d_max) {
+    NEED_CTX(c);
+    if (!x || !d_max) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    if (n) HIPCHK(c, launch_max_abs_f32(x, n, d_max, c->stream));
     return SARX_OK;
 }
 
@@ -1210,6 +1274,16 @@ int sarx_allgather_dev(sarx_ctx* c, const void* send, void* recv, size_t bytes_p
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->comm_fence, 0));
     ncclResult_t r = g_rccl.AllGather(send, recv, bytes_per_rank / 4, ncclFloat32, c->comm, c->comm_stream);
     if (r != ncclSuccess) return fail(c, SARX_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return SARX_OK;
+}
+int sarx_allreduce_max_dev(sarx_ctx* c, float* d_buf, size_t count) {
+    NEED_CTX(c);
+    if (!c->comm) return fail(c, SARX_ERR_COMM, "communicator not initialised");
+    if (!d_buf || !count) return fail(c, SARX_ERR_INVALID, "bad all-reduce arguments");
+    HIPCHK(c, hipEventRecord(c->comm_fence, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->comm_fence, 0));
+    ncclResult_t r = g_rccl.AllReduce(d_buf, d_buf, count, ncclFloat32, ncclMax, c->comm, c->comm_stream);
+    if (r != ncclSuccess) return fail(c, SARX_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return SARX_OK;
 }
 int sarx_comm_sync(sarx_ctx* c) { NEED_CTX(c); HIPCHK(c, hipStreamSynchronize(c->comm_stream)); return SARX_OK; }

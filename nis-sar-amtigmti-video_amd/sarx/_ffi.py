@@ -59,6 +59,8 @@ SIGNATURES = {
     "sarx_device_info": (_i, [_vp, C.c_char_p, _sz, _P(_i), _P(_u64), C.c_char_p, _sz]),
     "sarx_malloc": (_i, [_vp, _sz, _P(_vp)]),
     "sarx_free": (_i, [_vp, _vp]),
+    "sarx_host_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "sarx_host_free": (_i, [_vp, _vp]),
     "sarx_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "sarx_ati_dpca_masked_dev": (_i, [_vp, _vp, _vp, _sz, _d, _vp, _f, _P(AtiOutputs)]),
     "sarx_mask_phase_frac_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
     "sarx_magnitude_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_max_abs_f32_dev": (_i, [_vp, _vp, _sz, _vp]),
     "sarx_mask_phase_dev": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
     "sarx_corner_turn_dev": (_i, [_vp, _vp, _vp, _i, _i]),
     "sarx_multilook_dev": (_i, [_vp, _vp, _vp, _i, _i, _i]),
@@ -109,6 +112,7 @@ SIGNATURES = {
     "sarx_rccl_info": (_i, [C.c_char_p, _sz, _P(_i), _P(_i)]),
     "sarx_comm_init": (_i, [_vp, _vp, _i, _i]),
     "sarx_allgather_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_allreduce_max_dev": (_i, [_vp, _vp, _sz]),
     "sarx_comm_sync": (_i, [_vp]),
     "sarx_comm_fence_compute": (_i, [_vp]),
     "sarx_comm_mark": (_i, [_vp, _i]),

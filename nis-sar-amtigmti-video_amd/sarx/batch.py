@@ -49,6 +49,9 @@ class LocalStackComm:
     def all_gather(self, slot):
         return np.asarray(slot)[None]
 
+    def all_reduce_max(self, value):
+        return float(value)
+
     def finish(self):
         pass
 
@@ -69,6 +72,13 @@ class TorchStackComm:
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t, group=self.group)
         return np.stack([o.numpy() for o in out], axis=0)
+
+    def all_reduce_max(self, value):
+        """max over ranks of one float: the collective of the global normalisation (sar_batch_sim.py:337)."""
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
 
     def finish(self):
         pass
@@ -132,6 +142,14 @@ class RcclStackComm:
 
     def close(self):
         self.ctx.lib.sarx_comm_destroy(self.ctx.h)
+
+
+def global_max_host(local_frames, comm):
+    """g_max = max([np.max(np.abs(fr)) for fr in frames]) over ALL ranks' frames (sar_batch_sim.py:337-338, 0 -> 1.0): every
+    rank reduces the frames it focused itself, one float crosses the transport - nobody needs the gathered stack for it."""
+    local = max((float(np.max(np.abs(fr))) for fr in local_frames if np.size(fr)), default=0.0)
+    g_max = comm.all_reduce_max(local)
+    return g_max if g_max > 0 else 1.0
 
 
 def run_batch_host(frame_ids_all, world, rank, process_frame, comm, slot_shape=None):
@@ -364,6 +382,26 @@ class TwoChannelBatch:
         if self.rccl and self.world > 1:
             ctx.comm_sync()
 
+    def global_max(self):
+        """g_max of the whole stack (sar_batch_sim.py:337-338: max over all frames of max|frame|; 0 -> 1.0) without reading the
+        gathered stack: every rank reduces the slots of its OWN frames on the device (sarx_max_abs_f32_dev), then one float is
+        all-reduced with max - ncclAllReduce on the comm stream (sarx_allreduce_max_dev), the gloo group on the host-transport
+        fallback, nothing at world 1.  Call after run(); synchronises (the value is returned to the host)."""
+        from ._ffi import check
+        ctx = self.ctx
+        if not hasattr(self, "d_gmax"):
+            self.d_gmax = ctx.alloc(4)
+        check(ctx.lib.sarx_memset(ctx.h, self.d_gmax.ptr, 0, 4), ctx.h)
+        for i in range(len(self.mine)):
+            ctx.max_abs(_Ptr(self._slot_ptr(i, self.rank)), self.slot_bytes // 4, self.d_gmax)
+        if self.rccl and self.world > 1:
+            ctx.allreduce_max(self.d_gmax, 1)
+            ctx.comm_sync()
+        g = float(self.d_gmax.download(np.float32, (1,))[0])
+        if self.world > 1 and not self.rccl:
+            g = self.host_comm.all_reduce_max(g)
+        return g if g > 0 else 1.0
+
     def stack(self, frames=None):
         """The assembled [n_frames, H, W] float32 stack (or the listed frames of it) on the host."""
         if frames is None:
@@ -378,4 +416,6 @@ class TwoChannelBatch:
     def close(self):
         for b in (self.s1, self.s2, self.masked, self.d_stack, self.d_max, *self.outs.values(), *(x for pair in self._alloc for x in pair)):
             b.release()
+        if hasattr(self, "d_gmax"):
+            self.d_gmax.release()
         self.plan.close()

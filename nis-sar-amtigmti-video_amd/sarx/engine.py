@@ -2,6 +2,8 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
+import threading
 import weakref
 
 import numpy as np
@@ -41,7 +43,7 @@ class DeviceBuffer:
         return self
 
     def download(self, dtype, shape):
-        out = np.empty(shape, dtype=dtype)
+        out = self.ctx.pinned_empty(shape, dtype)            # large results: page-locked pool (one DMA, no first touch)
         if out.nbytes > self.nbytes:
             raise ValueError("download larger than buffer")
         check(self.ctx.lib.sarx_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes), self.ctx.h)
@@ -107,8 +109,26 @@ class DeviceArray:
             self.buf.release()
 
 
+class _PinnedBlock:
+    """A page-locked host block (sarx_host_alloc) behind the array interface.  NumPy keeps the object providing the interface
+    alive as the base of every array and view made on it; when the last of them dies the block goes back to its context's pool."""
+
+    def __init__(self, ctx, ptr, nbytes):
+        self._ctx, self._ptr, self._nbytes = ctx, ptr, nbytes
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self._ctx._pinned_return(self._ptr, self._nbytes)
+        except Exception:
+            pass
+
+
 class Context:
     """sarx_ctx wrapper: one per GPU, owns a compute stream and a comm stream."""
+
+    PINNED_MIN_BYTES = 64 << 20        # smaller results are plain NumPy arrays (the library copies them with one hipMemcpy anyway)
+    PINNED_FREE_PER_SIZE = 2           # free blocks kept per size; a caller that holds results alive gets fresh blocks
 
     def __init__(self, device_id=0):
         self.lib = _ffi.load()
@@ -118,6 +138,10 @@ class Context:
         self.device_id = int(device_id)
         self._live = {}
         self._plans = weakref.WeakSet()
+        self._pinned_free = {}         # nbytes -> [ptr, ...]
+        self._pinned_total = 0         # bytes handed out + bytes kept free
+        self._pinned_cap = int(float(os.environ.get("SARX_PINNED_POOL_GIB", "16")) * 2 ** 30)
+        self._pinned_lock = threading.Lock()
 
     def close(self):
         if self.h is not None:
@@ -126,8 +150,48 @@ class Context:
             for ptr in list(self._live.values()):
                 self.lib.sarx_free(self.h, ptr)
             self._live.clear()
+            with self._pinned_lock:
+                for ptrs in self._pinned_free.values():
+                    for ptr in ptrs:
+                        self.lib.sarx_host_free(self.h, ptr)
+                self._pinned_free.clear()
             self.lib.sarx_destroy(self.h)
             self.h = None
+
+    # -- pooled page-locked result arrays --
+    def pinned_empty(self, shape, dtype):
+        """np.empty(shape, dtype) on page-locked memory from a per-context pool (results of the *_host entry points): the
+        download is one DMA at the PCIe rate and a second call of the same size pays neither hipHostMalloc nor the first touch
+        of fresh pages.  The array is the caller's like any NumPy result; its block returns to the pool when the array and all
+        views of it are gone.  Small results, an exhausted pool budget (SARX_PINNED_POOL_GIB, default 16) or a failed pinned
+        allocation give an ordinary np.empty."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if nbytes < self.PINNED_MIN_BYTES or self.h is None:
+            return np.empty(shape, dtype)
+        with self._pinned_lock:
+            free = self._pinned_free.get(nbytes)
+            ptr = free.pop() if free else None
+            if ptr is None:
+                if self._pinned_total + nbytes > self._pinned_cap:
+                    return np.empty(shape, dtype)
+                out = C.c_void_p()
+                if self.lib.sarx_host_alloc(self.h, nbytes, C.byref(out)) != 0 or not out.value:
+                    return np.empty(shape, dtype)
+                ptr = out.value
+                self._pinned_total += nbytes
+        return np.asarray(_PinnedBlock(self, ptr, nbytes)).view(dtype).reshape(shape)
+
+    def _pinned_return(self, ptr, nbytes):
+        with self._pinned_lock:
+            if self.h is None:             # context closed first: the block outlives it (freed with the process)
+                return
+            free = self._pinned_free.setdefault(nbytes, [])
+            if len(free) < self.PINNED_FREE_PER_SIZE:
+                free.append(ptr)
+            else:
+                self.lib.sarx_host_free(self.h, ptr)
+                self._pinned_total -= nbytes
 
     def __del__(self):
         try:
@@ -237,6 +301,14 @@ class Context:
     def allgather(self, send, recv, bytes_per_rank):
         check(self.lib.sarx_allgather_dev(self.h, send.ptr, recv.ptr, int(bytes_per_rank)), self.h)
 
+    def max_abs(self, buf, n, d_max):
+        """*d_max = max(*d_max, max|buf[:n]|) over an fp32 device buffer (sarx_max_abs_f32_dev); clear d_max first."""
+        check(self.lib.sarx_max_abs_f32_dev(self.h, buf.ptr, int(n), d_max.ptr), self.h)
+
+    def allreduce_max(self, buf, count=1):
+        """In-place RCCL all-reduce(max) of `count` floats on the comm stream, ordered after the compute stream."""
+        check(self.lib.sarx_allreduce_max_dev(self.h, buf.ptr, int(count)), self.h)
+
     def comm_fence_compute(self):
         """Later compute-stream work waits (on the device) for every gather enqueued so far."""
         check(self.lib.sarx_comm_fence_compute(self.h), self.h)
@@ -286,8 +358,10 @@ class CsaPlan:
         check(self.ctx.lib.sarx_csa_plan_bytes(self.h, C.byref(b)), self.ctx.h)
         return b.value
 
-    def focus_host(self, phist_c64):
-        """[n_az x n_rg] complex64 host array -> focused image in the plan's layout (host)."""
+    def focus_host(self, phist_c64, out=None):
+        """[n_az x n_rg] complex64 host array -> focused image in the plan's layout (host).  The result array comes from the
+        context's page-locked pool (Context.pinned_empty) unless `out` - a C-contiguous complex64 array of the result's shape,
+        e.g. an earlier result - is given."""
         a = np.asarray(phist_c64)
         wide = a.dtype == np.complex128 and a.flags.c_contiguous        # the reference's dtype: narrowed by the library's copy threads
         if not wide:
@@ -295,7 +369,11 @@ class CsaPlan:
         if a.shape != (self.n_az, self.n_rg):
             raise ValueError(f"phist shape {a.shape} != plan ({self.n_az}, {self.n_rg})")
         shape = (self.n_rg, self.n_az) if self.rg_major else (self.n_az, self.n_rg)
-        out = np.empty(shape, dtype=np.complex64)
+        if out is None:
+            out = self.ctx.pinned_empty(shape, np.complex64)
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.complex64 and out.shape == shape and out.flags.c_contiguous
+                  and out.flags.writeable):
+            raise ValueError(f"out must be a writeable C-contiguous complex64 array of shape {shape}")
         fn = self.ctx.lib.sarx_csa_focus_host_c128 if wide else self.ctx.lib.sarx_csa_focus_host
         check(fn(self.h, a.ctypes.data, out.ctypes.data), self.ctx.h)
         return out

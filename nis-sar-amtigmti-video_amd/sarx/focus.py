@@ -33,7 +33,7 @@ def clear_plan_cache():
 
 def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
                   platform_speed_mps, range_ref_m, t_start_fast, *, ctx=None, fuse_range=True,
-                  materialize_transpose=False):
+                  materialize_transpose=False, out=None):
     """Chirp Scaling focus on the GPU; drop-in for the reference function of the
     same name (sar_ati_dcpa_sim_csa.py:202-396).
 
@@ -46,6 +46,12 @@ def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     ``materialize_transpose=True`` corner-turns on the GPU instead and returns a
     C-contiguous [N_rg x N_az] array.  ``pulse_width_sec`` is accepted and
     unused, exactly as in the reference.
+
+    The image array is allocated per call as in the reference; for results of
+    64 MiB and more it sits on page-locked memory from a small per-context pool
+    (Context.pinned_empty), so the download is one DMA and a second call pays no
+    first touch.  ``out`` = the image a previous call returned (or any complex64
+    array of that shape and layout) is overwritten and returned instead.
     """
     on_device = isinstance(phist, DeviceArray)          # echoes synthesised with device=True: nothing is uploaded
     if on_device:
@@ -69,7 +75,10 @@ def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
         img = d_img.download(np.complex64, (n_rg, n_az) if materialize_transpose else (n_az, n_rg))
         d_img.release()
     else:
-        img = plan.focus_host(a)              # complex128 input is narrowed inside the library while it is staged
+        dst = None
+        if out is not None:
+            dst = out if materialize_transpose else out.T      # the [n_az x n_rg] memory behind the img.T view
+        img = plan.focus_host(a, out=dst)      # complex128 input is narrowed inside the library while it is staged
     range_axis, cross_range_axis = plan.axes()
     return (img if materialize_transpose else img.T), range_axis, cross_range_axis
 
@@ -208,34 +217,37 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
         keep = set()
     d_raw = None if on_device else ctx.alloc(n * 8)
     try:
-        try:                                                # channel 1: image + max|image| out of the same launch
-            plan.set_max_slot(bufs["d_max"])
-            have_max = True
-        except _ffi.SarxError:
-            have_max = False
-        if on_device:
-            plan.focus_dev(r1, bufs["slc1"])
-        else:
-            d_raw.upload(r1)
-            plan.focus_dev(d_raw, bufs["slc1"])
-            ctx.sync()                                      # d_raw is about to be overwritten
-            d_raw.upload(r2)
-        src2 = r2 if on_device else d_raw
         fused = False
-        if have_max and not unmasked_phase:
-            try:                                            # channel 2: the products come out of its last azimuth launch
-                plan.set_ati(bufs["slc1"], bufs["d_max"], mask_frac, cal_phase, bufs["ati_phase_masked"], bufs["slc1_mag"],
-                             bufs["dpca_mag"], keep_image=return_slc2)
-                fused = True
+        have_max = False
+        try:                                                # one guard around both focuses and both uploads: the cached plan
+            try:                                            # never keeps a pointer to a buffer released below
+                plan.set_max_slot(bufs["d_max"])            # channel 1: image + max|image| out of the same launch
+                have_max = True
             except _ffi.SarxError:
-                fused = False
-        try:
+                have_max = False
+            if on_device:
+                plan.focus_dev(r1, bufs["slc1"])
+            else:
+                d_raw.upload(r1)
+                plan.focus_dev(d_raw, bufs["slc1"])
+                ctx.sync()                                  # d_raw is about to be overwritten
+                d_raw.upload(r2)
+            src2 = r2 if on_device else d_raw
+            if have_max and not unmasked_phase:
+                try:                                        # channel 2: the products come out of its last azimuth launch
+                    plan.set_ati(bufs["slc1"], bufs["d_max"], mask_frac, cal_phase, bufs["ati_phase_masked"], bufs["slc1_mag"],
+                                 bufs["dpca_mag"], keep_image=return_slc2)
+                    fused = True
+                except _ffi.SarxError:
+                    fused = False
+            if have_max and not fused:
+                # without the ATI epilogue armed a focus clears the slot and reduces max|its own image| into it: channel 2's
+                # focus must not see it, or the 5 % threshold below would come from max|slc2| instead of max|slc1| (:447)
+                plan.set_max_slot(None)
             plan.focus_dev(src2, bufs["slc2"])
         finally:
-            if fused:
-                plan.set_ati(None)
-            if have_max:
-                plan.set_max_slot(None)
+            plan.set_ati(None)
+            plan.set_max_slot(None)
         if not fused:
             if unmasked_phase or not have_max:              # ATI launch, then the mask with the threshold taken on the device
                 bufs["ati_phase"] = ctx.alloc(n * 4)

@@ -5,6 +5,8 @@ in-place RCCL all-gather."""
 import os
 import sys
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # rank start, before `import sarx` / any GPU call (dmabuf IPC for RCCL)
+
 import numpy as np
 import torch.distributed as dist
 
@@ -31,6 +33,7 @@ def main():
     ctx.sync()
     whole = b.d_stack.download(np.float32, (b.n_rounds * comm.world, *b.slot_shape))      # pad slots included
     np.save(os.path.join(out, f"stack64_rank{comm.rank}.npy"), whole)
+    np.save(os.path.join(out, f"gmax64_rank{comm.rank}.npy"), np.array([b.global_max()]))
     b.close()
     dist.barrier()
     dist.destroy_process_group()

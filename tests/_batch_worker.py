@@ -3,6 +3,8 @@ host arrays.  The per-frame engine here is the CPU oracle (test stand-in for the
 import os
 import sys
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # rank start, before anything can touch a GPU (dmabuf IPC for RCCL)
+
 import numpy as np
 import torch.distributed as dist
 
@@ -26,6 +28,9 @@ def main():
     comm = batch.TorchStackComm()
     stack = batch.run_batch_host(list(range(n_frames)), comm.world, comm.rank, frame_slot, comm)
     np.save(os.path.join(out, f"stack_rank{comm.rank}.npy"), stack)
+    # the global display maximum (sar_batch_sim.py:337-338) from each rank's OWN frames + one all-reduce(max)
+    mine = [stack[f] for f in batch.shard_frames(n_frames, comm.world, comm.rank)]
+    np.save(os.path.join(out, f"gmax_rank{comm.rank}.npy"), np.array([batch.global_max_host(mine, comm)]))
     dist.barrier()
     dist.destroy_process_group()
 

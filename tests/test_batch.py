@@ -98,3 +98,31 @@ def test_two_rank_gloo_stack_equals_single_process(tmp_path, n_frames):
     single = np.stack([w.frame_slot(f) for f in range(n_frames)])
     assert s0.shape == single.shape == (n_frames, 16, 16)
     np.testing.assert_array_equal(s0, single)                # N-rank stack == 1-rank stack, bit for bit
+
+
+def test_eight_rank_gloo_thirteen_frames(tmp_path):
+    """The 8-GPU launch shape on the CPU: 13 frames on 8 ranks (two rounds, the second with five frames and three pad
+    slots, ranks 5-7 own one frame only).  Every rank ends with the whole stack = the one-process stack bit for bit, and the
+    global maximum from own-frames + all-reduce(max) equals the maximum of the gathered stack on every rank."""
+    n_frames, world = 13, 8
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_batch_worker.py"), str(tmp_path), str(n_frames)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _batch_worker as w
+    single = np.stack([w.frame_slot(f) for f in range(n_frames)])
+    for rank in range(world):
+        s = np.load(tmp_path / f"stack_rank{rank}.npy")
+        assert s.shape == (n_frames, 16, 16)
+        np.testing.assert_array_equal(s, single)
+        assert float(np.load(tmp_path / f"gmax_rank{rank}.npy")[0]) == float(np.abs(single).max())
+
+
+def test_global_max_host_local_and_empty():
+    c = batch.LocalStackComm()
+    assert batch.global_max_host([np.array([[1.0, -3.0]]), np.array([[2.0]])], c) == 3.0
+    assert batch.global_max_host([], c) == 1.0                       # a rank without frames / an all-zero stack: 0 -> 1.0 (:338)
+    assert batch.global_max_host([np.zeros((2, 2))], c) == 1.0

@@ -212,11 +212,18 @@ def test_two_ranks_one_gpu_equal_single_rank(tmp_path, stack, n, frames):
     b.run()
     ctx.sync()
     single = b.stack()
+    g_single = b.global_max()
     b.close()
     rounds = -(-frames // 2)
     assert s0.shape[0] == 2 * rounds
     np.testing.assert_array_equal(s0[:frames], single)           # N-rank stack == 1-rank stack, bit for bit, frame order
     assert (s0[frames:] == 0).all()                              # the pad slot of the last round is zeros, not a stale slot
+    # global normalisation (sar_batch_sim.py:337-338): own-frames reduction on the device + all-reduce(max) over the ranks
+    # = the maximum of the gathered stack, on every rank and on one rank alone
+    g = float(np.abs(single).max())
+    assert g_single == g > 0
+    for r in (0, 1):
+        assert float(np.load(tmp_path / f"gmax64_rank{r}.npy")[0]) == g
 
 
 @pytest.mark.parametrize("stack", ["multilook", "products"])
@@ -242,4 +249,6 @@ def test_rccl_two_gpus_equal_single_rank(tmp_path, stack):
     ctx.sync()
     np.testing.assert_array_equal(s0[:frames], b.stack())
     assert (s0[frames:] == 0).all()
+    for r in (0, 1):                                             # ncclAllReduce(max) of the per-rank maxima
+        assert float(np.load(tmp_path / f"gmax64_rank{r}.npy")[0]) == b.global_max() == float(np.abs(s0).max())
     b.close()

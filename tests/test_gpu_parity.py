@@ -218,6 +218,70 @@ def test_two_channel_end_to_end(sx):
         np.testing.assert_array_equal(lean[key], res[key])
 
 
+def test_host_call_results_come_from_a_page_locked_pool(sx, ctx):
+    """sar_focus_csa(numpy) -> numpy, the call a maintainer makes (:410-411): results of 64 MiB and more sit on page-locked
+    blocks of a per-context pool.  A result stays the caller's while it is alive (a second call gets another block), its block is
+    reused once it is gone, `out=` overwrites an earlier result in place, and every variant returns the same image bit for bit."""
+    raw, k = orc.point_scene(2048, 4096, seed=3, n_targets=3)            # 64 MiB image
+    args = orc.focus_args(k)
+    a, ra, ca = sx.sar_focus_csa(raw, *args, ctx=ctx)
+    assert a.shape == (4096, 2048) and a.T.flags.c_contiguous
+    addr_a = a.T.ctypes.data
+    b, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx)                      # a is still alive: b must not alias it
+    assert b.T.ctypes.data != addr_a
+    np.testing.assert_array_equal(a, b)
+    ref = a.copy()
+    del a
+    import gc
+    gc.collect()
+    c, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx)                      # a's block is back in the pool and is handed out again
+    assert c.T.ctypes.data == addr_a
+    np.testing.assert_array_equal(c, ref)
+    b[...] = 0
+    d, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx, out=b)               # an earlier result as the destination
+    assert d.T.ctypes.data == b.T.ctypes.data
+    np.testing.assert_array_equal(b, ref)
+    plain = np.zeros((4096, 2048), np.complex64)                         # any array with the img.T layout works as out
+    with pytest.raises(ValueError):
+        sx.sar_focus_csa(raw, *args, ctx=ctx, out=plain)                 # C-contiguous [n_rg x n_az] is the wrong layout for the view
+    e, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx, out=np.zeros((2048, 4096), np.complex64).T)
+    np.testing.assert_array_equal(e, ref)
+    from sarx.engine import _PinnedBlock
+
+    def root(x):
+        while getattr(x, "base", None) is not None:
+            x = x.base
+        return x
+    assert isinstance(root(c), _PinnedBlock)
+    small, ks = orc.point_scene(256, 256, seed=3, n_targets=3)
+    s_img, _, _ = sx.sar_focus_csa(small, *orc.focus_args(ks), ctx=ctx)   # small results stay ordinary arrays
+    assert not isinstance(root(s_img), _PinnedBlock)
+
+
+def test_two_channel_fallback_takes_the_threshold_from_channel_one(sx):
+    """Sizes without the fused ATI epilogue (here n_rg = 16: not a multiple of 32) accept the max slot but not set_ati; the
+    facade then runs the separate masked ATI launch, whose 5 % threshold must still be 0.05 * max|slc1| (:447) - channel 2's
+    focus must not re-reduce the slot.  Channel 2 is three times stronger here, so a threshold taken from it would mask
+    every pixel between 5 % and 15 % of max|slc1|."""
+    (r1, r2), k = orc.point_scene(64, 16, seed=5, clutter_db=-6.0, two_channel=True)
+    r2 = (3.0 * r2).astype(np.complex64)
+    args = orc.focus_args(k)
+    res = sx.focus_ati_dpca(r1, r2, *args, pulse_shift=False)
+    assert not res["fused_products"]
+    o1 = orc.sar_focus_csa(r1, *args)[0]
+    o2 = orc.sar_focus_csa(r2, *args)[0]
+    ref = orc.ati_dpca(o1, o2)
+    inside = ref["slc1_mag"] > 0.05 * ref["max_mag"] * (1 + 1e-4)
+    outside = ref["slc1_mag"] < 0.05 * ref["max_mag"] * (1 - 1e-4)
+    between = inside & (ref["slc1_mag"] < 0.15 * ref["max_mag"])
+    assert between.sum() > 10 and outside.sum() > 0
+    assert abs(res["max_mag"] - ref["max_mag"]) < 1e-5 * ref["max_mag"]
+    assert _masked_phase_err(res["ati_phase_masked"], ref["ati_phase"], inside) < TOL
+    assert (res["ati_phase_masked"][between] != 0).all()
+    assert (res["ati_phase_masked"][outside] == 0).all()
+    assert orc.rel_l2(res["slc1_mag"], ref["slc1_mag"]) < TOL
+
+
 def test_two_channel_facade_on_a_reused_workspace(sx, ctx):
     """focus_ati_dpca with device arrays in, device_output and a two_channel_workspace: nothing is allocated or fetched per
     call (fetch_stats=False: the call only enqueues), the planes equal the default call's bit for bit, and a second frame
@@ -479,3 +543,31 @@ def test_rccl_allgather_single_rank(sx, ctx):
     comm.finish()
     np.testing.assert_array_equal(d_r.download(np.float32, x.shape), x)
     ctx.lib.sarx_comm_destroy(ctx.h)
+
+
+def test_global_max_reduction_and_allreduce_single_rank(sx, ctx):
+    """The two halves of the stack's global normalisation (sar_batch_sim.py:337-338): sarx_max_abs_f32_dev folds max|x| of an
+    fp32 buffer into a device float (negative values, a tail that is not a multiple of four, accumulation over several
+    buffers), sarx_allreduce_max_dev is ncclAllReduce(max) on the comm stream - with a one-rank communicator the identity."""
+    from sarx import _ffi
+    from sarx.batch import RcclStackComm
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(1_000_003).astype(np.float32)
+    x[777_001] = -9.5
+    y = rng.standard_normal(4099).astype(np.float32) * 0.1
+    d_x, d_y, d_m = ctx.to_device(x), ctx.to_device(y), ctx.alloc(4)
+    _ffi.check(ctx.lib.sarx_memset(ctx.h, d_m.ptr, 0, 4), ctx.h)
+    ctx.max_abs(d_y, y.size, d_m)
+    assert d_m.download(np.float32, (1,))[0] == np.abs(y).max()
+    ctx.max_abs(d_x, x.size, d_m)
+    ctx.max_abs(d_y, y.size, d_m)                       # a smaller buffer afterwards does not lower it
+    assert d_m.download(np.float32, (1,))[0] == np.float32(9.5)
+    with pytest.raises(sx.SarxError):
+        ctx.allreduce_max(d_m, 1)                       # no communicator yet
+    comm = RcclStackComm(ctx, 1, 0)
+    ctx.allreduce_max(d_m, 1)
+    comm.finish()
+    assert d_m.download(np.float32, (1,))[0] == np.float32(9.5)
+    ctx.lib.sarx_comm_destroy(ctx.h)
+    for b in (d_x, d_y, d_m):
+        b.release()

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Wall time of the drop-in host-array call (sar_focus_csa on NumPy in, NumPy out): what a maintainer of the reference sees,
-PCIe included.  python3 tools/bench_hostpath.py [size=8192]"""
+"""Wall time of the drop-in host-array call (sar_focus_csa on NumPy in, NumPy out): what a maintainer of the reference sees
+at sar_ati_dcpa_sim_csa.py:410-411, PCIe included.
+    python3 tools/bench_hostpath.py [size=8192] [--json FILE]
+Reports the first call (plan creation, twiddles, hipHostMalloc of the result block), the steady state with the result
+allocated per call from the page-locked pool (results alternate between two blocks, as `img = f(raw)` in a loop does), the
+`out=` form, and the complex128 input of the reference's own arrays.  The floor is 2 x bytes / PCIe rate + the focus itself."""
+import json
 import os
 import sys
 import time
@@ -12,22 +17,64 @@ sys.path.insert(0, os.path.join(ROOT, "nis-sar-amtigmti-video_amd"))
 import sarx  # noqa: E402
 from sarx import radar  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 8192
+out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
 rng = np.random.default_rng(0)
-raw = (rng.standard_normal((n, n), dtype=np.float32) + 1j * rng.standard_normal((n, n), dtype=np.float32)).astype(np.complex64)
+raw = np.empty((n, n), np.complex64)
+for i0 in range(0, n, 1024):
+    blk = rng.standard_normal((min(1024, n - i0), n, 2), dtype=np.float32)
+    raw[i0:i0 + blk.shape[0]] = blk[..., 0] + 1j * blk[..., 1]
 args = radar.focus_args(n)
+res = {"size": n, "bytes_each_way": raw.nbytes, "calls_ms": [], "out_ms": [], "c128_ms": []}
+
+
+def timed(f):
+    t0 = time.perf_counter()
+    r = f()
+    return r, (time.perf_counter() - t0) * 1e3
+
+
+img = None
+for rep in range(6):
+    (img, rax, cax), ms = timed(lambda: sarx.sar_focus_csa(raw, *args))
+    res["calls_ms"].append(round(ms, 2))
+    print(f"sar_focus_csa {n}x{n} host in / host out, call {rep}: {ms:.1f} ms wall ({2 * raw.nbytes / ms / 1e6:.1f} GB/s over both directions)", flush=True)
+ref = img.copy() if n <= 8192 else None
 for rep in range(3):
-    t0 = time.perf_counter()
-    img, rax, cax = sarx.sar_focus_csa(raw, *args)
-    dt = time.perf_counter() - t0
-    print(f"sar_focus_csa {n}x{n} host in / host out: {dt * 1e3:.1f} ms wall ({2 * raw.nbytes / dt / 1e9:.1f} GB/s over both directions)")
-raw128 = raw.astype(np.complex128)
-for rep in range(2):
-    t0 = time.perf_counter()
-    img2, _, _ = sarx.sar_focus_csa(raw128, *args)
-    dt = time.perf_counter() - t0
-    print(f"sar_focus_csa {n}x{n} complex128 in (the reference's dtype) / complex64 out: {dt * 1e3:.1f} ms wall")
-assert np.array_equal(img, img2)
-t0 = time.perf_counter()
-raw128.astype(np.complex64)
-print(f"  (numpy astype(complex64) of that input alone: {(time.perf_counter() - t0) * 1e3:.1f} ms)")
+    (img2, _, _), ms = timed(lambda: sarx.sar_focus_csa(raw, *args, out=img))
+    res["out_ms"].append(round(ms, 2))
+    print(f"   ... out=<previous result>: {ms:.1f} ms", flush=True)
+if ref is not None:
+    assert np.array_equal(img2, ref)
+# device-resident focus alone, for the floor
+ctx = sarx.default_context()
+d_in, d_out = ctx.to_device(raw), ctx.alloc(raw.nbytes)
+plan = sarx.CsaPlan(ctx, n, n, *args, flags=sarx._ffi.FUSE_RANGE)
+plan.focus_dev(d_in, d_out)
+ctx.sync()
+ctx.record(0)
+for _ in range(5):
+    plan.focus_dev(d_in, d_out)
+ctx.record(1)
+res["focus_dev_ms"] = round(ctx.elapsed_ms(0, 1) / 5, 3)
+_, up = timed(lambda: d_in.upload(raw))
+pinned = ctx.pinned_empty(raw.shape, np.complex64)
+_, down = timed(lambda: sarx._ffi.check(ctx.lib.sarx_memcpy_d2h(ctx.h, pinned.ctypes.data, d_out.ptr, raw.nbytes), ctx.h))
+res["upload_pageable_ms"], res["download_pinned_ms"] = round(up, 2), round(down, 2)
+print(f"   parts: staged upload of the pageable input {up:.1f} ms ({raw.nbytes / up / 1e6:.1f} GB/s), focus {res['focus_dev_ms']:.2f} ms, "
+      f"download into a pooled page-locked result {down:.1f} ms ({raw.nbytes / down / 1e6:.1f} GB/s)", flush=True)
+plan.close(); d_in.release(); d_out.release()
+del pinned
+if n <= 8192:
+    raw128 = raw.astype(np.complex128)
+    for rep in range(2):
+        (img3, _, _), ms = timed(lambda: sarx.sar_focus_csa(raw128, *args))
+        res["c128_ms"].append(round(ms, 2))
+        print(f"sar_focus_csa {n}x{n} complex128 in (the reference's dtype) / complex64 out: {ms:.1f} ms wall", flush=True)
+    assert np.array_equal(img3, ref)
+res["steady_ms"] = min(res["calls_ms"][2:])
+res["floor_ms"] = round(res["upload_pageable_ms"] + res["focus_dev_ms"] + res["download_pinned_ms"], 2)
+print(json.dumps(res))
+if out_json:
+    with open(out_json, "w") as fh:
+        json.dump(res, fh, indent=1)
