@@ -43,6 +43,11 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="frames in flight per GPU: consecutive (independent) frames are enqueued on this many alternating compute lanes of the "
+                         "context, each lane with its own plan and buffers, so kernels of neighbouring frames overlap (1 = one frame at a time)")
+    ap.add_argument("--range-cus", type=int, default=None,
+                    help="compute units the persistent range launch sizes its grid for while frames are in flight (default 192 of 256; 0 = all)")
     ap.add_argument("--unfused", action="store_true", help="run range passes 2 and 3 as two launches")
     ap.add_argument("--passes", action="store_true", help="also print every pass alone to stderr")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -177,7 +182,7 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
     """BASELINE config 5 through the shared device driver; returns the block for the JSON line (rank 0) or None."""
     from sarx.batch import TwoChannelBatch
     b = TwoChannelBatch(ctx, a.batch_size, a.batch_frames, world, rank, stack=stack, looks=LOOKS, rccl=use_rccl and world > 1,
-                        host_comm=None if (use_rccl or world == 1) else host_comm, scene=a.batch_scene)
+                        host_comm=None if (use_rccl or world == 1) else host_comm, scene=a.batch_scene, lanes=a.in_flight)
     b.prepare()                                                  # echoes of this rank's frames resident in HBM before the clock
     b.run()                                                      # warm-up batch
     times = []
@@ -201,7 +206,7 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
     per_frame = ("focus(channel 1; its last launch also leaves max|slc1|" + (" and the multilooked stack slot" if stack == "multilook" else "") +
                  ") + focus(channel 2; its last launch emits masked ATI phase, |slc1|, DPCA magnitude and never writes slc2)"
                  if b.fused_ati else "focus x 2 + one ATI/DPCA launch" + (" with the mask inside" if b.fused_mask else " + one mask launch"))
-    n_rounds = b.n_rounds
+    n_rounds, lanes_used = b.n_rounds, b.lanes
     b.close()
     if rank != 0:
         return None
@@ -218,7 +223,7 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
                        f"frame f -> rank f mod {world}, every frame's two echo channels resident in HBM before the clock starts" +
                        (" (device noise)" if a.batch_scene == "noise" else " (C3 point-target scene, movers advanced by f * 0.1 s)"),
            "stack": what + f", {slot_bytes / 2**20:.0f} MiB per frame, gathered in place once per round of {world} frame(s)",
-           "per_frame": per_frame, "gather_bytes_per_rank_per_round": slot_bytes,
+           "per_frame": per_frame, "frames_in_flight_per_gpu": lanes_used, "gather_bytes_per_rank_per_round": slot_bytes,
            "gather_s_per_round_at_one_xgmi_link": link_s}
     if compute_round is not None:
         blk["compute_s_per_frame_one_gpu"] = compute_round
@@ -287,9 +292,17 @@ def main():
     n = a.size
     K, W = a.steps, a.warmup
     flags = 0 if a.unfused else _ffi.FUSE_RANGE
-    plan = sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=flags)
-    d_in, d_img = ctx.alloc(n * n * 8), ctx.alloc(n * n * 8)
-    ctx.fill_noise(d_in, n * n, 1000 + rank)
+    # Frames are independent (sar_batch_sim.py:303-331): frame s runs on lane s % L of the context, every lane with its own plan
+    # (scratch), its own echo and its own image, so the launches of neighbouring frames share the GPU - the issue-bound range launch
+    # of one frame beside the bandwidth-bound azimuth launches of the next.  Every step is still one whole focus of one frame.
+    L = max(1, min(a.in_flight, 4))
+    range_cus = a.range_cus if a.range_cus is not None else (192 if L > 1 else 0)
+    plans = [sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=flags) for _ in range(L)]
+    d_ins = [ctx.alloc(n * n * 8) for _ in range(L)]
+    d_imgs = [ctx.alloc(n * n * 8) for _ in range(L)]
+    for i in range(L):
+        ctx.fill_noise(d_ins[i], n * n, 1000 + rank + 7919 * i)
+    plan, d_in, d_img = plans[0], d_ins[0], d_imgs[0]
 
     # ---- collective: RCCL over xGMI; gloo through host memory only if RCCL cannot come up on every rank -------------
     use_rccl, host_comm, collective, rccl = False, None, None, None
@@ -310,7 +323,11 @@ def main():
             collective = "gloo all-gather through host memory (RCCL did not come up on every rank: see stderr)"
         d_recv = ctx.alloc(slot_bytes * world * 2)                # two round blocks, alternating
 
-    def step(s, mark):
+    def step(s, mark, lanes=L):
+        lane = s % lanes
+        ctx.select_lane(lane)
+        ctx.set_range_cus(range_cus if lanes > 1 else 0)      # frames in flight: the persistent range launch leaves CUs to the other lane
+        plan, d_in, d_img = plans[lane], d_ins[lane], d_imgs[lane]
         if mark and 2 * s + 1 < 256:
             plan.mark_range(2 * s, 2 * s + 1)
         else:
@@ -354,12 +371,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # dominant kernel = the range pass; events were recorded on the kernel's own stream
+    # dominant kernel = the range pass; events were recorded on the kernel's own stream (the lane the frame ran on)
     marked = min(K, 127)
     rg_ms = sum(ctx.elapsed_ms(2 * s, 2 * s + 1) for s in range(marked)) / max(marked, 1)
     launches = 1 if not a.unfused else 2
     alg_bytes = 16.0 * n * n * launches            # one c64 read + one c64 write per sample per launch
     achieved = alg_bytes / (rg_ms * 1e-3) / 1e9
+
+    # the same steps with ONE frame in flight (lane 0 only): a frame's own latency, and the range launch with the GPU to itself
+    solo = None
+    if L > 1:
+        Ks = min(K, 40)
+        for s in range(2):
+            step(s, False, lanes=1)
+        barrier()
+        t1 = time.perf_counter()
+        for s in range(Ks):
+            step(s, True, lanes=1)
+        barrier()
+        dt1 = time.perf_counter() - t1
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt1], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt1 = float(t.item())
+        rg1 = sum(ctx.elapsed_ms(2 * s, 2 * s + 1) for s in range(Ks)) / Ks
+        solo = {"steps": Ks, "ms_per_step": dt1 / Ks * 1e3, "value": world * Ks / dt1, "range_launch_ms": rg1 / launches,
+                "range_achieved_GBps": alg_bytes / (rg1 * 1e-3) / 1e9}
+    ctx.select_lane(0)
+    ctx.set_range_cus(0)
 
     probe = d_img.download(np.complex64, (4, n))
     assert np.isfinite(probe).all() and np.abs(probe).max() > 0, "focused image is not finite / all zero"
@@ -443,7 +483,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "c64 (phase arguments f64)", "data": "synthetic",
             "config": {"workload": f"{n}x{n} complex64 single-channel CSA focus, echo resident in HBM",
-                       "frames_per_step_per_gpu": 1, "range_passes": "fused 2+3" if not a.unfused else "separate",
+                       "frames_per_step_per_gpu": 1, "frames_in_flight_per_gpu": L, "range_launch_cus": range_cus if L > 1 else "all",
+                       "range_passes": "fused 2+3" if not a.unfused else "separate",
                        "image_layout": "[n_az x n_rg]; img.T returned as a view like the reference",
                        "parallelism": f"frames sharded 1/GPU x{world}" +
                                       (f"; 16x16 multilook slot fused into the focus + {collective} per step" if collective else "")},
@@ -455,6 +496,16 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": rg_ms / launches,
                          "algorithmic_bytes_per_launch": 16.0 * n * n},
         }
+        line["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SARX_")}      # kernel-form switches in effect
+        if solo is not None:
+            line["roofline"]["note"] = (f"measured live in the timed region, where {L} frames are in flight: launches of neighbouring frames share "
+                                        "the GPU, so this launch's own duration stretches while the frame rate rises; roofline_solo is the same "
+                                        "launch with the GPU to itself")
+            line["one_frame_in_flight"] = {"ms_per_step": solo["ms_per_step"], "value": solo["value"], "unit": "frames/s", "steps": solo["steps"],
+                                           "note": "the same steps on lane 0 only, timed after the headline region: one frame's latency"}
+            line["roofline_solo"] = dict(line["roofline"], achieved=solo["range_achieved_GBps"], frac=solo["range_achieved_GBps"] / HBM_PEAK_GBS,
+                                         launch_ms=solo["range_launch_ms"],
+                                         note="one frame in flight: HIP events around the range launch of every step of the one_frame_in_flight region")
         if collective:
             line["collective"] = {"transport": collective, "ranks": world, "rccl": rccl}
             # false = RCCL did not come up on every rank and the slots travelled through host memory (a rehearsal on fewer devices
@@ -480,9 +531,10 @@ def main():
             line["passes"] = per_pass
 
     # the config-4 buffers make room for config 5
-    plan.close()
-    d_in.release()
-    d_img.release()
+    for x in plans:
+        x.close()
+    for x in d_ins + d_imgs:
+        x.release()
     if d_recv is not None:
         d_recv.release()
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 204   /* 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
+#define SARX_VERSION 204   /* 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join); 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -109,7 +109,21 @@ int sarx_memcpy2d_d2h(sarx_ctx* ctx, void* dst_host, size_t dst_pitch, const voi
 int sarx_memcpy2d_h2d(sarx_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch,
                       size_t width, size_t height);
 int sarx_memset(sarx_ctx* ctx, void* dst_dev, int value, size_t bytes);
-int sarx_sync(sarx_ctx* ctx);
+int sarx_sync(sarx_ctx* ctx);      /* waits for every lane and the comm stream */
+/* Lanes: a ctx owns up to four compute streams; lane 0 exists from sarx_init.  sarx_select_lane makes every LATER enqueue of
+ * this ctx (focus, passes, products, memset, events) go to that lane's stream.  The frames of a batch are independent
+ * (sar_batch_sim.py:303-331), so consecutive frames may be enqueued on alternating lanes - each lane with its OWN plan and its
+ * own buffers - and kernels of neighbouring frames then share the GPU: the issue-bound range launch of one frame beside the
+ * bandwidth-bound azimuth launches of the next (16384^2: 4.39 -> 3.93 ms per frame with two frames in flight).  Results are
+ * bit-identical to one lane.  sarx_lanes_join: on the device, every lane waits for everything enqueued so far on every lane.
+ * Blocking host copies and sarx_sync wait for all lanes. */
+int sarx_select_lane(sarx_ctx* ctx, int lane);
+int sarx_lanes_join(sarx_ctx* ctx);
+/* With frames in flight the persistent fused range launch (16384-sample lines: one 136 KiB-LDS workgroup per CU, which no azimuth
+ * tile can share a CU with) should leave part of the chip to the other lane's azimuth launches: its grid is sized for `cus`
+ * compute units instead of all of them (0 = all, the default; 192 of 256 measured best with two lanes: 3.93-3.96 ms per 16384^2
+ * frame on every box met, against 4.1-4.3 ms when both lanes ask for the whole chip).  Results do not depend on it. */
+int sarx_set_range_cus(sarx_ctx* ctx, int cus);
 /* HIP events on the ctx stream: record `slot` (0..255); elapsed ms between two recorded slots */
 int sarx_event_record(sarx_ctx* ctx, int slot);
 int sarx_event_elapsed_ms(sarx_ctx* ctx, int slot_start, int slot_stop, float* out_ms);

@@ -8,10 +8,6 @@
 #include "phase.hpp"
 #include "ati_pixel.hpp"
 
-#ifndef RG_ABL
-#define RG_ABL 0     // ablation builds only (tools/gpu_r3x.sh), fused mode: bit 0 no global loads, bit 1 no global stores, bit 2 no phases - results are wrong
-#endif
-
 namespace sarx {
 
 // ------------------------------------------------------------------------------
@@ -57,10 +53,7 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
 #pragma unroll
         for (int b = 0; b < P / R0; ++b)
 #pragma unroll
-            for (int r = 0; r < R0; ++r) {
-                if constexpr ((RG_ABL & 1) != 0 && MODE == RG_FUSED) v[b * R0 + r] = make_float2((float)t * 1e-3f + (float)(b * R0 + r), 1.f + (float)row * 1e-6f);
-                else v[b * R0 + r] = src[E::in_index(t, b, r)];
-            }
+            for (int r = 0; r < R0; ++r) v[b * R0 + r] = src[E::in_index(t, b, r)];
         stockham_run<N, 1, false, false>(v, t, 0, my_lds, a.tw);
         constexpr int RL = E::R_last;
         if constexpr (MODE == RG_FFT) {
@@ -92,7 +85,7 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
                 for (int mm = 0; mm < P / 2; ++mm) {
                     const int m = half * (P / 2) + mm;
                     const int reg = (m % B) * RL + m / B;
-                    if constexpr ((RG_ABL & 4) == 0 || MODE != RG_FUSED) v[reg] = cmul(v[reg], q.next());
+                    v[reg] = cmul(v[reg], q.next());
                     if constexpr (MODE == RG_FFT_PHI2) {
                         if (live) dst[t + T * m] = v[reg];
                     }
@@ -126,15 +119,9 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
 #pragma unroll
         for (int m = 0; m < P; ++m) {
             const int reg = (m % B) * RL + m / B;
-            cf y;
-            if constexpr ((RG_ABL & 4) != 0 && MODE == RG_FUSED) y = make_float2(v[reg].x * s, v[reg].y * s);
-            else {
-                cf ph = q.next();
-                ph.x *= s; ph.y *= s;
-                y = cmul(v[reg], ph);
-            }
-            if constexpr ((RG_ABL & 2) != 0 && MODE == RG_FUSED) { if (y.x == 12345.678f) dst[t + T * m] = y; }
-            else if (live) dst[t + T * m] = y;
+            cf ph = q.next();
+            ph.x *= s; ph.y *= s;
+            if (live) dst[t + T * m] = cmul(v[reg], ph);
         }
         return;
     }

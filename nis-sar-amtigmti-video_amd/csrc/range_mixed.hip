@@ -9,7 +9,7 @@
 // (bins t + r N/25) and the spectrum never leaves them.  One HBM round trip of the unpadded line instead of the
 // five padded ones of the chirp-z route (32768-point convolution).
 //
-// Where the fused launch's 0.63 ms at 7199 x 13200 go (ablation builds, MIX_ABL below; profiles/r03_q_range_mixed_ablation.log):
+// Where the fused launch's 0.63 ms at 7199 x 13200 go (ablation builds, tools/ablation_switches.patch; profiles/r03_q_range_mixed_ablation.log):
 // without any global load or store 0.54 ms; without the butterflies and twiddles 0.38 ms; with neither - the four LDS crossings,
 // eight barriers and the two phase generators alone - 0.25 ms.  The launch is bound by its own instruction stream and LDS
 // exchanges running in lockstep (ten waves, one workgroup per CU: the 103 KiB image leaves no room for a second line), not by HBM:
@@ -23,9 +23,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef MIX_ABL
-#define MIX_ABL 0            // ablation builds only (tools/gpu_r3q.sh): bit 0 no global loads, bit 1 no global stores, bit 2 no butterflies / twiddles - results are wrong
-#endif
 #ifndef MIX_PREFETCH
 #define MIX_PREFETCH 1       // FFT . x . IFFT modes: the next line's first-stage inputs are loaded during this line's inverse half (two bursts)
 #endif
@@ -139,8 +136,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
 #pragma unroll
         for (int r = 0; r < R1; ++r)
             if (r >= r0 && r < r1) {
-                if constexpr ((MIX_ABL & 1) != 0) dstv[r] = make_float2((float)t * 1e-3f + (float)r, 1.f + (float)(size_t)p * 1e-20f);
-                else if constexpr (MODE == RG_CONV) dstv[r] = (t + r * G1 < a.conv_valid) ? ld8<false>(p + t + r * G1) : make_float2(0.f, 0.f);
+                if constexpr (MODE == RG_CONV) dstv[r] = (t + r * G1 < a.conv_valid) ? ld8<false>(p + t + r * G1) : make_float2(0.f, 0.f);
                 else dstv[r] = ld8<false>(p + t + r * G1);
             }
     };
@@ -198,7 +194,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                 } else {
                     load_first_stage(v, src, t, 0, R1);      // RG_CONV: the line is shorter than the transform, zeros beyond it are never read
                 }
-                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R1, false>(v);
+                mix::dft_any<R1, false>(v);
             }
             cross(t, G1, G2,
                   [&](auto cc) { constexpr int CC = decltype(cc)::value;
@@ -208,8 +204,8 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                   nothing);
             // stage 2: radix R2, NS = R1
             if (t < G2) {
-                if constexpr ((MIX_ABL & 4) == 0) mix_twiddle<R2, R1, false>(v, t);
-                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R2, false>(v);
+                mix_twiddle<R2, R1, false>(v, t);
+                mix::dft_any<R2, false>(v);
             }
             __syncthreads();                            // every read of the image is finished
             cross(t, G2, G3,
@@ -220,8 +216,8 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                   nothing);
             // stage 3: radix R3, NS = R1 R2; thread t ends with bins k = t + r G3
             if (t < G3) {
-                if constexpr ((MIX_ABL & 4) == 0) mix_twiddle<R3, R1 * R2, false>(v, t);
-                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R3, false>(v);
+                mix_twiddle<R3, R1 * R2, false>(v, t);
+                mix::dft_any<R3, false>(v);
                 if constexpr (MODE == RG_CONV) {      // times the filter spectrum, bins k = t + r G3 (the inverse starts from these registers)
                     const cf* __restrict__ mv = a.mulvec;
 #pragma unroll
@@ -258,7 +254,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
 #pragma unroll
                     for (int r = 0; r < R3; ++r) v[r] = src[t + r * G3];
                 }
-                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R3, true>(v);
+                mix::dft_any<R3, true>(v);
             }
             if constexpr (FWD) __syncthreads();         // forward stage 3's reads of the image are finished
             cross(t, G3, G2,
@@ -269,8 +265,8 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                   [&] { if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, 0, NPF / 2); } });
             // stage 2: radix R2, NS = R3
             if (t < G2) {
-                if constexpr ((MIX_ABL & 4) == 0) mix_twiddle<R2, R3, true>(v, t);
-                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R2, true>(v);
+                mix_twiddle<R2, R3, true>(v, t);
+                mix::dft_any<R2, true>(v);
             }
             __syncthreads();
             cross(t, G2, G1,
@@ -281,8 +277,8 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                   [&] { if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, NPF / 2, NPF); } });
             // stage 3: radix R1, NS = R3 R2; thread t ends with samples n = t + r G1
             if (t < G1) {
-                if constexpr ((MIX_ABL & 4) == 0) mix_twiddle<R1, R3 * R2, true>(v, t);
-                if constexpr ((MIX_ABL & 4) == 0) mix::dft_any<R1, true>(v);
+                mix_twiddle<R1, R3 * R2, true>(v, t);
+                mix::dft_any<R1, true>(v);
                 const float s = a.inv_n;
                 if constexpr (MODE == RG_CONV) {      // only the cropped window is written
 #pragma unroll
@@ -300,7 +296,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                         cf ph = q.next();
                         ph.x *= s; ph.y *= s;
                         const cf y = cmul(v[r], ph);
-                        if ((MIX_ABL & 2) == 0 || y.x == 12345.678f) st8<false>(dst + t + r * G1, y);
+                        st8<false>(dst + t + r * G1, y);
                     }
                 }
             }

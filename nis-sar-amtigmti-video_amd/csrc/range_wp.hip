@@ -47,15 +47,9 @@
 #define WP_PREFETCH 6        // next line's loads: 0 none, 1 one burst before the wave-private phase, 2 one burst at the top of the line,
 #endif                       // 3 four groups spread over the wave-private phase, 4 two groups in the head + two in it, 5 two bursts of eight (start / middle of it),
                              // 6 the same two bursts taking every other access each
-#ifndef WP_WITH_FUSED
-#define WP_WITH_FUSED 0      // also build FFT.Phi2.IFFT.Phi3 in one launch on this structure (tools/rgbench.hip): 128 VGPRs cannot hold its twiddles
-#endif                       // (spills 28-156 B/lane) and it loses to range_fused_wl.hip (1.18-1.25 vs 1.09-1.12 ms), so the library does not ship it
 #ifndef WP_LAYOUT
 #define WP_LAYOUT 1          // spectrum order between the two passes: 0 = P[q*1024 + k2] (a wave's 8 KiB contiguous), 1 = P'[kf*1024 + q*64 + lane],
 #endif                       // k2 = lane + 64 kf (the sixteen waves of a workgroup fill each 8 KiB chunk together, like the natural-order side)
-#ifndef WP_ABL
-#define WP_ABL 0             // ablation builds (tools/rgbench.hip): 1 = no arithmetic (loads, exchanges, stores only), 2 = no exchanges either
-#endif
 #ifndef WP_HOIST
 #define WP_HOIST 4           // bit 0: cross twiddles W_N^(t q) kept in registers (30), bit 1: W_1024^(l ka) (30), bit 2: W_64^(l_lo ke) (6)
 #endif
@@ -132,27 +126,18 @@ template <int WHICH> __device__ __forceinline__ void make_tw(Tw& tw, int t) {
 template <class HOOK>
 __device__ __forceinline__ void fwd1024(cf* v, int l, cf* row, const Tw& tw, HOOK hook) {
     hook(0);
-#if WP_ABL == 0
     dft16<false>(v);
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw.t1[k]);
-#endif
     hook(1);
-#if WP_ABL < 2
     swap_lane45_reg01(v);
-#endif
-#if WP_ABL == 0
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         dft4<false>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 #pragma unroll
         for (int ke = 1; ke < 4; ++ke) v[4 * c + ke] = cmul(v[4 * c + ke], tw.t2[ke]);
     }
-#endif
     hook(2);
-#if WP_ABL == 2
-    return;
-#endif
     // element (ka = (l >> 4) + 4 c, ke, l_lo) -> register l_lo of lane ka + 16 ke
     cf* wr = row + (l & 15) * PF + (l >> 4);
     exchange_sync<true>();
@@ -165,21 +150,14 @@ __device__ __forceinline__ void fwd1024(cf* v, int l, cf* row, const Tw& tw, HOO
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = rd[r * PF];
     hook(3);
-#if WP_ABL == 0
     dft16<false>(v);
-#endif
 }
 // its mirror: in v[kf] = Y[lane + 64 kf], out v[r] = 1024 * y[l + 64 r]
 template <class HOOK>
 __device__ __forceinline__ void inv1024(cf* v, int l, cf* row, const Tw& tw, HOOK hook) {
     hook(0);
-#if WP_ABL == 0
     dft16<true>(v);
-#endif
     hook(1);
-#if WP_ABL == 2
-    return;
-#endif
     cf* wr = row + l;
     exchange_sync<true>();
 #pragma unroll
@@ -191,33 +169,24 @@ __device__ __forceinline__ void inv1024(cf* v, int l, cf* row, const Tw& tw, HOO
 #pragma unroll
         for (int ke = 0; ke < 4; ++ke) v[4 * c + ke] = rd[4 * c + 16 * ke];
     hook(2);
-#if WP_ABL == 0
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int ke = 1; ke < 4; ++ke) v[4 * c + ke] = cmulc(v[4 * c + ke], tw.t2[ke]);
         dft4<true>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
     }
-#endif
     swap_lane45_reg01(v);
     hook(3);
-#if WP_ABL == 0
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmulc(v[k], tw.t1[k]);
     dft16<true>(v);
-#endif
 }
 
 // forward head: v[n1] = x[n1*1024 + t] -> wave w holds y_w[l + 64 r]
 __device__ __forceinline__ void fwd_head(cf* v, int t, cf* lds, const Tw& tw, bool lead_barrier) {
-#if WP_ABL == 0
     dft16<false>(v);
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw.cw[q]);
-#endif
-#if WP_ABL == 2
-    return;
-#endif
     if (lead_barrier) __syncthreads();          // every wave has finished with its row of the previous line
 #pragma unroll
     for (int q = 0; q < 16; ++q) lds[q * ROW + t] = v[q];
@@ -228,9 +197,6 @@ __device__ __forceinline__ void fwd_head(cf* v, int t, cf* lds, const Tw& tw, bo
 }
 // inverse tail: wave w holds 1024 * y_w[l + 64 r] -> v[n1] = N * x[n1*1024 + t]
 __device__ __forceinline__ void inv_tail(cf* v, int t, cf* lds, const Tw& tw) {
-#if WP_ABL == 2
-    return;
-#endif
     cf* wr = lds + (t >> 6) * ROW + (t & 63);
     exchange_sync<true>();
 #pragma unroll
@@ -238,11 +204,9 @@ __device__ __forceinline__ void inv_tail(cf* v, int t, cf* lds, const Tw& tw) {
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = lds[q * ROW + t];
-#if WP_ABL == 0
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], tw.cw[q]);
     dft16<true>(v);
-#endif
 }
 
 // registers [4 g0, 4 g1) of a line: 16 accesses STRIDE samples apart (1024: natural order, 64: permuted spectrum)
@@ -337,9 +301,7 @@ __global__ __launch_bounds__(wp::THREADS, 4) void range_wp_kernel(RangeArgs a) {
             if constexpr (!INV && WP_PREFETCH == 1) prefetch_all();
             if constexpr (!INV && WP_PREFETCH == 4) group(1);
             fwd1024(v, l, myrow, tw, hook);
-#if WP_ABL == 0
             if constexpr (MODE != RG_FFT) apply_phi2(v, w, l, sload_double2(a.c2 + row), a.df);
-#endif
             if constexpr (!INV) {
 #pragma unroll
                 for (int kf = 0; kf < 16; ++kf)
@@ -351,13 +313,13 @@ __global__ __launch_bounds__(wp::THREADS, 4) void range_wp_kernel(RangeArgs a) {
             }
         }
         if constexpr (INV) {
-            if constexpr (!FWD) { if (WP_ABL < 2 && line != (int)blockIdx.x) __syncthreads(); }    // the previous line's column reads of this wave's row are done
+            if constexpr (!FWD) { if (line != (int)blockIdx.x) __syncthreads(); }    // the previous line's column reads of this wave's row are done
             inv1024(v, l, myrow, tw, hook);
             inv_tail(v, t, lds, tw);
             if constexpr (!FWD && WP_PREFETCH == 1) prefetch_all();
             if constexpr (!FWD && WP_PREFETCH == 4) group(1);
             const float sc = a.inv_n;
-            if constexpr (MODE == RG_IFFT || WP_ABL != 0) {
+            if constexpr (MODE == RG_IFFT) {
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) st8<NTS>(dst + t + n1 * M, make_float2(v[n1].x * sc, v[n1].y * sc));
             } else {
@@ -395,9 +357,6 @@ hipError_t launch_range_wp(int mode, const RangeArgs& a, int cus, hipStream_t st
         case RG_IFFT: return launch_wp<RG_IFFT>(a, cus, st);
         case RG_FFT_PHI2: return launch_wp<RG_FFT_PHI2>(a, cus, st);
         case RG_IFFT_PHI3: return launch_wp<RG_IFFT_PHI3>(a, cus, st);
-#if WP_WITH_FUSED
-        case RG_FUSED: return launch_wp<RG_FUSED>(a, cus, st);
-#endif
     }
     return hipErrorInvalidValue;
 }

@@ -90,7 +90,11 @@ static bool load_rccl(std::string& err) {
 struct sarx_ctx {
     int device = -1;
     int cus = 256;                     // compute units of this device (persistent grids are sized from it)
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the CURRENT lane's stream: everything is enqueued here
+    static constexpr int LANES = 4;
+    hipStream_t lane[LANES] = {};      // lane 0 = the stream made by sarx_init; the others on first sarx_select_lane
+    hipEvent_t lane_ev[LANES] = {};
+    int cur_lane = 0;
     hipStream_t comm_stream = nullptr;
     static constexpr int SLAB_STREAMS = 8;
     hipStream_t slab_stream[SLAB_STREAMS] = {};   // slab mode with SARX_SLAB_STREAMS > 1: independent tile groups on concurrent streams
@@ -103,9 +107,12 @@ struct sarx_ctx {
     hipEvent_t comm_mark[4] = {};      // sarx_comm_mark / sarx_comm_wait_mark: "gathers enqueued up to here are finished"
     bool comm_mark_set[4] = {};
     float2* tw_all = nullptr;          // table for size n at offset n: exp(-2 pi i m/n)
-    float* ati_part_max = nullptr;     // reduction scratch
-    double2* ati_part_sum = nullptr;
-    double* ati_out3 = nullptr;
+    float* ati_part_max_all = nullptr;     // reduction scratch, one set per lane (two frames in flight must not share it)
+    double2* ati_part_sum_all = nullptr;
+    double* ati_out3_all = nullptr;
+    float* ati_part_max_() const { return ati_part_max_all + (size_t)cur_lane * 4096; }
+    double2* ati_part_sum_() const { return ati_part_sum_all + (size_t)cur_lane * 4096; }
+    double* ati_out3_() const { return ati_out3_all + (size_t)cur_lane * 4; }
     // staged host transfers (sarx_memcpy_h2d / _d2h and the *_host entry points, large pageable buffers): COPY_THREADS host
     // threads, each with its own pinned chunk and stream, copy chunk by chunk in parallel with the DMA of the others
     static constexpr int COPY_THREADS = 8;
@@ -115,6 +122,7 @@ struct sarx_ctx {
     std::mutex copy_mu;                // the pinned chunks and copy streams are per-ctx state: one staged copy at a time
     ncclComm_t comm = nullptr;
     int n_ranks = 0, rank = 0;
+    int range_cus = 0;                 // > 0: persistent range launches size their grid for this many CUs (sarx_set_range_cus; frames in flight)
     int range_impl = 0;                // SARX_RANGE_IMPL: 0 auto, 1 = 16 pts/thread, 2 = 32 pts/thread split exchange, 3 = fused wave-private, 4 = sixteen-wave permuted-spectrum pair
     std::string err;
 };
@@ -163,13 +171,20 @@ static int fail(sarx_ctx* c, int code, const char* fmt, ...) {
             return fail((c), SARX_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// every lane's stream (sarx_select_lane): host-visible operations are ordered after all of them
+static hipError_t sync_all_lanes(sarx_ctx* c) {
+    for (int k = 0; k < sarx_ctx::LANES; ++k)
+        if (c->lane[k]) { hipError_t e = hipStreamSynchronize(c->lane[k]); if (e != hipSuccess) return e; }
+    return hipSuccess;
+}
+
 // Host <-> device copy of a large pageable buffer.  hipMemcpy from pageable memory runs at 8 GB/s here and into untouched
 // memory (a fresh NumPy array) at 13 GB/s (tools/pcibench.hip); eight threads staging 32 MiB chunks through pinned buffers reach
 // 51-54 GB/s both ways.  Blocking; ordered after everything on the ctx stream.  Small copies take the plain path.
 // narrow: (host -> device only) the host buffer holds complex128 and is rounded to complex64 on the way into the pinned chunk
 // (the reference's arrays are complex128; a NumPy astype of 2^28 elements costs more than the whole transfer)
 static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, bool narrow = false) {
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = sync_all_lanes(c);
     if (e != hipSuccess) return e;
     if (!narrow && bytes >= 4 * sarx_ctx::COPY_CHUNK) {
         // a buffer from sarx_host_alloc (page-locked, already faulted in) needs no staging: one DMA at the PCIe rate, no host memcpy,
@@ -281,7 +296,9 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
     c->device = device_id;
     if (prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
     if (const char* e2 = getenv("SARX_RANGE_IMPL")) c->range_impl = (e2[0] == 'v') ? atoi(e2 + 1) : atoi(e2);
+    if (const char* e2 = getenv("SARX_RANGE_CUS")) c->range_cus = atoi(e2);
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->lane[0] = c->stream;
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     for (int i = 0; i < N_EVENTS; ++i) HIPCHK(nullptr, hipEventCreate(&c->ev[i]));
     HIPCHK(nullptr, hipEventCreateWithFlags(&c->comm_fence, hipEventDisableTiming));
@@ -297,9 +314,9 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
         }
     HIPCHK(nullptr, hipMalloc(&c->tw_all, tw.size() * sizeof(float2)));
     HIPCHK(nullptr, hipMemcpy(c->tw_all, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
-    HIPCHK(nullptr, hipMalloc(&c->ati_part_max, 4096 * sizeof(float)));
-    HIPCHK(nullptr, hipMalloc(&c->ati_part_sum, 4096 * sizeof(double2)));
-    HIPCHK(nullptr, hipMalloc(&c->ati_out3, 3 * sizeof(double)));
+    HIPCHK(nullptr, hipMalloc(&c->ati_part_max_all, sarx_ctx::LANES * 4096 * sizeof(float)));
+    HIPCHK(nullptr, hipMalloc(&c->ati_part_sum_all, sarx_ctx::LANES * 4096 * sizeof(double2)));
+    HIPCHK(nullptr, hipMalloc(&c->ati_out3_all, sarx_ctx::LANES * 4 * sizeof(double)));
     *out_ctx = c;
     return SARX_OK;
 }
@@ -309,7 +326,7 @@ int sarx_destroy(sarx_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    hipFree(c->tw_all); hipFree(c->ati_part_max); hipFree(c->ati_part_sum); hipFree(c->ati_out3);
+    hipFree(c->tw_all); hipFree(c->ati_part_max_all); hipFree(c->ati_part_sum_all); hipFree(c->ati_out3_all);
     for (int i = 0; i < N_EVENTS; ++i) hipEventDestroy(c->ev[i]);
     hipEventDestroy(c->comm_fence);
     hipEventDestroy(c->comm_done);
@@ -323,7 +340,11 @@ int sarx_destroy(sarx_ctx* c) {
         if (c->slab_ev[k]) hipEventDestroy(c->slab_ev[k]);
     }
     if (c->slab_fork) hipEventDestroy(c->slab_fork);
-    hipStreamDestroy(c->stream);
+    for (int k = 0; k < sarx_ctx::LANES; ++k) {
+        if (c->lane_ev[k]) hipEventDestroy(c->lane_ev[k]);
+        if (k > 0 && c->lane[k]) hipStreamDestroy(c->lane[k]);
+    }
+    hipStreamDestroy(c->lane[0]);
     hipStreamDestroy(c->comm_stream);
     delete c;
     return SARX_OK;
@@ -382,6 +403,7 @@ int sarx_memcpy2d_d2h(sarx_ctx* c, void* d, size_t dpitch, const void* s, size_t
     NEED_CTX(c);
     if (!d || !s || width > dpitch || width > spitch) return fail(c, SARX_ERR_INVALID, "bad 2-D copy arguments");
     if (!width || !height) return SARX_OK;
+    HIPCHK(c, sync_all_lanes(c));
     HIPCHK(c, hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SARX_OK;
@@ -390,14 +412,41 @@ int sarx_memcpy2d_h2d(sarx_ctx* c, void* d, size_t dpitch, const void* s, size_t
     NEED_CTX(c);
     if (!d || !s || width > dpitch || width > spitch) return fail(c, SARX_ERR_INVALID, "bad 2-D copy arguments");
     if (!width || !height) return SARX_OK;
+    HIPCHK(c, sync_all_lanes(c));
     HIPCHK(c, hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SARX_OK;
 }
 int sarx_memset(sarx_ctx* c, void* d, int v, size_t n) { NEED_CTX(c); HIPCHK(c, hipMemsetAsync(d, v, n, c->stream)); return SARX_OK; }
+int sarx_select_lane(sarx_ctx* c, int lane) {
+    NEED_CTX(c);
+    if (lane < 0 || lane >= sarx_ctx::LANES) return fail(c, SARX_ERR_INVALID, "lane %d out of range [0,%d)", lane, sarx_ctx::LANES);
+    if (!c->lane[lane]) HIPCHK(c, hipStreamCreateWithFlags(&c->lane[lane], hipStreamNonBlocking));
+    c->cur_lane = lane;
+    c->stream = c->lane[lane];
+    return SARX_OK;
+}
+int sarx_set_range_cus(sarx_ctx* c, int cus) {
+    NEED_CTX(c);
+    if (cus < 0) return fail(c, SARX_ERR_INVALID, "cus must be >= 0 (0 = all)");
+    c->range_cus = cus;
+    return SARX_OK;
+}
+int sarx_lanes_join(sarx_ctx* c) {
+    NEED_CTX(c);
+    for (int k = 0; k < sarx_ctx::LANES; ++k) {
+        if (!c->lane[k]) continue;
+        if (!c->lane_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->lane_ev[k], c->lane[k]));
+    }
+    for (int k = 0; k < sarx_ctx::LANES; ++k)
+        for (int j = 0; j < sarx_ctx::LANES; ++j)
+            if (j != k && c->lane[k] && c->lane[j]) HIPCHK(c, hipStreamWaitEvent(c->lane[k], c->lane_ev[j], 0));
+    return SARX_OK;
+}
 int sarx_sync(sarx_ctx* c) {
     NEED_CTX(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all_lanes(c));
     HIPCHK(c, hipStreamSynchronize(c->comm_stream));
     return SARX_OK;
 }
@@ -507,7 +556,7 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
 int sarx_csa_plan_destroy(sarx_plan* p) {
     if (!p) return SARX_OK;
     hipSetDevice(p->ctx->device);
-    hipStreamSynchronize(p->ctx->stream);
+    sync_all_lanes(p->ctx);
     general_csa_destroy(p->gen);
     hipFree(p->c1); hipFree(p->c2); hipFree(p->c3);
     hipFree(p->ati_part);
@@ -644,7 +693,7 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
                     (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 16384 && mode != RG_FUSED));
     // impl 3 (default for the fused launch at 16384): wave-private sub-transforms
     if (mode == RG_FUSED && range_fused_wl_supported(p->n_rg) && (c->range_impl == 3 || c->range_impl == 0))
-        return launch_range_fused_wl(a, c->cus, c->stream);
+        return launch_range_fused_wl(a, (c->range_cus > 0 && c->range_cus < c->cus) ? c->range_cus : c->cus, c->stream);
     return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->cus, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
 }
 
@@ -661,7 +710,7 @@ static void ati_args(const sarx_plan* p, AzArgs& a) {
 static int ati_finish(sarx_plan* p) {
     if (!p->ati_s1) return SARX_OK;
     sarx_ctx* c = p->ctx;
-    HIPCHK(c, launch_ati_finish_sums(p->ati_part, p->ati_nparts, p->ati_thr, p->ati_part + p->ati_nparts, c->ati_out3, c->stream));
+    HIPCHK(c, launch_ati_finish_sums(p->ati_part, p->ati_nparts, p->ati_thr, p->ati_part + p->ati_nparts, c->ati_out3_(), c->stream));
     return SARX_OK;
 }
 static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, void* out, int q0, int nq) {
@@ -945,7 +994,7 @@ int sarx_rda_plan_create(sarx_ctx* c, int n_ranges, int n_pulses, const sarx_rad
 int sarx_rda_plan_destroy(sarx_rda_plan* p) {
     if (!p) return SARX_OK;
     hipSetDevice(p->ctx->device);
-    hipStreamSynchronize(p->ctx->stream);
+    sync_all_lanes(p->ctx);
     rda_destroy(p->r);
     hipFree(p->d_in);
     delete p;
@@ -1013,16 +1062,16 @@ static int ati_dpca_impl(sarx_ctx* c, const void* s1, const void* s2, size_t n, 
     a.ati_phase = o->ati_phase; a.mag1 = o->slc1_mag; a.dpca_mag = o->dpca_mag;
     a.interf = (float2*)o->ati_interf; a.diff = (float2*)o->dpca_diff;
     a.mag2 = o->slc2_mag; a.ph1 = o->slc1_phase; a.ph2 = o->slc2_phase; a.dpca_phase = o->dpca_phase;
-    a.part_max = c->ati_part_max; a.part_sum = c->ati_part_sum;
+    a.part_max = c->ati_part_max_(); a.part_sum = c->ati_part_sum_();
     a.thr_max = d_max; a.mask_frac = mask_frac;
     // the two images are read for the last time here: nontemporal loads once they are too large to still be cached
     // (0.341 -> 0.329 ms at 8192^2); SARX_ATI_NT=0/1 overrides
     { static const int nt = [] { const char* e = getenv("SARX_ATI_NT"); return e ? atoi(e) : -1; }(); a.nt = nt < 0 ? n >= ((size_t)1 << 25) : nt != 0; }
     HIPCHK(c, launch_ati_dpca(a, c->stream));
-    HIPCHK(c, launch_ati_finish(c->ati_part_max, c->ati_part_sum, ati_blocks(n), c->ati_out3, c->stream));
+    HIPCHK(c, launch_ati_finish(c->ati_part_max_(), c->ati_part_sum_(), ati_blocks(n), c->ati_out3_(), c->stream));
     if (max_mag || sum2) {
         double h[3];
-        HIPCHK(c, hipMemcpyAsync(h, c->ati_out3, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h, c->ati_out3_(), sizeof h, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (max_mag) *max_mag = h[0];
         if (sum2) { sum2[0] = h[1]; sum2[1] = h[2]; }
@@ -1033,7 +1082,7 @@ static int ati_dpca_impl(sarx_ctx* c, const void* s1, const void* s2, size_t n, 
 int sarx_ati_stats(sarx_ctx* c, double* max_mag, double* sum2) {
     NEED_CTX(c);
     double h[3];
-    HIPCHK(c, hipMemcpyAsync(h, c->ati_out3, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h, c->ati_out3_(), sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (max_mag) *max_mag = h[0];
     if (sum2) { sum2[0] = h[1]; sum2[1] = h[2]; }
@@ -1044,7 +1093,7 @@ int sarx_mask_phase_frac_dev(sarx_ctx* c, const float* phase, const float* mag, 
     NEED_CTX(c);
     if (!phase || !mag || !out) return fail(c, SARX_ERR_INVALID, "NULL pointer");
     if (n == 0) return SARX_OK;
-    HIPCHK(c, launch_mask_phase_frac(phase, mag, n, frac, c->ati_out3, out, c->stream));
+    HIPCHK(c, launch_mask_phase_frac(phase, mag, n, frac, c->ati_out3_(), out, c->stream));
     return SARX_OK;
 }
 
@@ -1159,7 +1208,7 @@ int sarx_tdbp_plan_create(sarx_ctx* c, int n_pulses, int num_samples, int nx, in
 int sarx_tdbp_plan_destroy(sarx_tdbp_plan* p) {
     if (!p) return SARX_OK;
     hipSetDevice(p->ctx->device);
-    hipStreamSynchronize(p->ctx->stream);
+    sync_all_lanes(p->ctx);
     tdbp_destroy(p->t);
     hipFree(p->d_raw);
     delete p;

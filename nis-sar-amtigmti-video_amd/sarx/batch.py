@@ -218,7 +218,7 @@ class TwoChannelBatch:
 
     def __init__(self, ctx, n, n_frames, world=1, rank=0, stack="multilook", looks=16, rccl=False, host_comm=None,
                  seed_base=1000, flags=None, mask_frac=0.05, resident=True, fused_mask=True, fused_ati=True, scene="noise",
-                 scene_scale=1.0):
+                 scene_scale=1.0, lanes=2):
         from . import _ffi, radar
         from .engine import CsaPlan
         if stack not in STACKS:
@@ -241,17 +241,25 @@ class TwoChannelBatch:
         args = radar.focus_args(n) if scene == "noise" else (self.k["Lambda"], self.k["T_p"], self.k["Kr"], self.k["FS"], self.k["PRF"],
                                                              self.k["V_eff"], self.k["R0"], self.k["t_start_fast"])
         self.focus_args = args
-        self.plan = CsaPlan(ctx, n, n, *args, flags=_ffi.FUSE_RANGE if flags is None else flags)
-        self.s1, self.s2 = ctx.alloc(px * 8), ctx.alloc(px * 8)
-        self.outs = {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
-        self.masked = ctx.alloc(px * 4)
+        # Frames in flight: this rank's i-th frame runs on compute lane i % lanes of the context (sarx_select_lane), every lane
+        # with its own plan (scratch), image buffers and product planes, so the launches of consecutive frames overlap on the GPU.
+        # Results do not depend on it (same kernels, separate buffers).
+        self.lanes = max(1, min(int(lanes), 4))
+        self.range_cus = 192                # of 256: sarx_set_range_cus while frames are in flight (only the persistent 16384-sample launch looks at it)
+        self._lane_state = []
+        for _ in range(self.lanes):
+            st = {"plan": CsaPlan(ctx, n, n, *args, flags=_ffi.FUSE_RANGE if flags is None else flags),
+                  "s1": ctx.alloc(px * 8), "s2": ctx.alloc(px * 8),
+                  "outs": {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")},
+                  "masked": ctx.alloc(px * 4), "d_max": ctx.alloc(_ffi.MAX_SLOT_BYTES)}
+            self._lane_state.append(st)
+        self._cur = 0
         # the 5 % mask inside the ATI launch: channel 1's focus leaves max|slc1| in d_max while it writes the image
         # (sarx_csa_plan_set_max_slot), so no further pass over the phase and magnitude planes is needed
         self.fused_mask = bool(fused_mask)
         # ... and the ATI / DPCA products out of channel 2's last azimuth launch (sarx_csa_plan_set_ati): slc2 is never written,
         # neither image is read again; sizes without that epilogue keep the separate launch
         self.fused_ati = bool(fused_ati) and self.fused_mask and n % 64 == 0
-        self.d_max = ctx.alloc(_ffi.MAX_SLOT_BYTES)
         self.slot_shape = (n // looks, n // looks) if stack == "multilook" else (n, n) if stack == "magnitude" else (3, n, n)
         self.slot_bytes = int(np.prod(self.slot_shape)) * 4
         self.n_rounds = rounds(self.n_frames, self.world)
@@ -261,12 +269,25 @@ class TwoChannelBatch:
         # (BASELINE config 5: inputs in HBM before the clock starts; 1 GiB per 8192^2 two-channel frame, 64 GiB for the
         # whole batch on one GPU of 288 GB); otherwise one pair of buffers refilled inside run() frame by frame
         self.resident = bool(resident)
-        n_buf = len(self.mine) if self.resident else 1
+        n_buf = len(self.mine) if self.resident else self.lanes          # not resident: one refilled pair per lane
         rows = self.n + (1 if scene == "c3" else 0)                    # c3: one more pulse, consumed by the DPCA pulse shift
         self._alloc = [(ctx.alloc(rows * self.n * 8), ctx.alloc(rows * self.n * 8)) for _ in range(max(n_buf, 1))]
         # what the focuser reads: the buffers themselves, or (c3) rx1[1:], rx2[:-1] as views
         self.raw = [(_Ptr(a.ptr + (self.n * 8 if scene == "c3" else 0)), _Ptr(b.ptr)) for a, b in self._alloc]
         self._prepared = False
+
+    # the current lane's plan and buffers
+    plan = property(lambda self: self._lane_state[self._cur]["plan"])
+    s1 = property(lambda self: self._lane_state[self._cur]["s1"])
+    s2 = property(lambda self: self._lane_state[self._cur]["s2"])
+    outs = property(lambda self: self._lane_state[self._cur]["outs"])
+    masked = property(lambda self: self._lane_state[self._cur]["masked"])
+    d_max = property(lambda self: self._lane_state[self._cur]["d_max"])
+
+    def use_lane(self, lane):
+        """Later focus_frame calls run on compute lane `lane` with that lane's plan and buffers."""
+        self._cur = int(lane) % self.lanes
+        self.ctx.select_lane(self._cur)
 
     # -- one frame -------------------------------------------------------------------------------------------
     def synth_frame(self, f, slot):
@@ -360,12 +381,15 @@ class TwoChannelBatch:
         from ._ffi import check
         ctx = self.ctx
         self.prepare()
+        if self.lanes > 1:
+            ctx.set_range_cus(self.range_cus)                       # persistent range launches leave CUs to the other lane's azimuth tiles
         for i in range(self.n_rounds):
+            self.use_lane(i)
             mine_ptr = self._slot_ptr(i, self.rank)
             if i < len(self.mine):
-                bufs = self.raw[i] if self.resident else self.raw[0]
+                bufs = self.raw[i] if self.resident else self.raw[i % self.lanes]
                 if not self.resident:
-                    self.synth_frame(self.mine[i], 0)
+                    self.synth_frame(self.mine[i], i % self.lanes)
                 self.focus_frame(bufs, mine_ptr)
                 self.write_slot(mine_ptr)
             else:                                                   # pad round: zeros, never a stale slot
@@ -379,6 +403,10 @@ class TwoChannelBatch:
                 check(ctx.lib.sarx_memcpy_d2h(ctx.h, slot.ctypes.data, mine_ptr, self.slot_bytes), ctx.h)
                 block = np.ascontiguousarray(self.host_comm.all_gather(slot))
                 check(ctx.lib.sarx_memcpy_h2d(ctx.h, self._slot_ptr(i, 0), block.ctypes.data, block.nbytes), ctx.h)
+        self.use_lane(0)
+        if self.lanes > 1:
+            ctx.set_range_cus(0)
+            ctx.lanes_join()                                        # whatever follows on any lane sees every frame finished
         if self.rccl and self.world > 1:
             ctx.comm_sync()
 
@@ -414,8 +442,12 @@ class TwoChannelBatch:
         return out
 
     def close(self):
-        for b in (self.s1, self.s2, self.masked, self.d_stack, self.d_max, *self.outs.values(), *(x for pair in self._alloc for x in pair)):
+        self.ctx.select_lane(0)
+        for b in (self.d_stack, *(x for pair in self._alloc for x in pair)):
             b.release()
+        for st in self._lane_state:
+            for b in (st["s1"], st["s2"], st["masked"], st["d_max"], *st["outs"].values()):
+                b.release()
+            st["plan"].close()
         if hasattr(self, "d_gmax"):
             self.d_gmax.release()
-        self.plan.close()

@@ -207,6 +207,20 @@ class Context:
         arr = np.ascontiguousarray(arr)
         return self.alloc(arr.nbytes).upload(arr)
 
+    def select_lane(self, lane):
+        """Every later enqueue of this context goes to compute stream `lane` (0..3): consecutive independent frames on
+        alternating lanes - each with its own plan and buffers - overlap on the GPU (sarx_select_lane)."""
+        check(self.lib.sarx_select_lane(self.h, int(lane)), self.h)
+
+    def set_range_cus(self, cus):
+        """Persistent range launches size their grid for `cus` compute units (0 = all): with frames in flight the rest of the
+        chip stays available to the other lane's azimuth launches (sarx_set_range_cus)."""
+        check(self.lib.sarx_set_range_cus(self.h, int(cus)), self.h)
+
+    def lanes_join(self):
+        """On the device: every lane waits for everything enqueued so far on every lane."""
+        check(self.lib.sarx_lanes_join(self.h), self.h)
+
     def sync(self):
         check(self.lib.sarx_sync(self.h), self.h)
 

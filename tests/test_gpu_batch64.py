@@ -53,7 +53,10 @@ def test_config5_64_frames_two_channel_8192():
     ctx.sync()
     st = b.stack()
     assert st.shape == (frames, n // 16, n // 16) and np.isfinite(st).all() and st.min() > 0
-    # the last frame's products are still in the driver's buffers: two different channels went through ATI/DPCA
+    # the last frame's products are still in the buffers of the lane it ran on (frame i of this rank -> lane i % lanes):
+    # two different channels went through ATI/DPCA
+    assert b.lanes == 2
+    b.use_lane(frames - 1)
     mx, sm = ctx.ati_stats()
     assert mx > 0 and abs(sm) > 0
     masked = b.masked.download(np.float32, (8, n))
@@ -74,6 +77,7 @@ def test_config5_64_frames_two_channel_8192():
     thr = np.float32(mx) * np.float32(0.05)
     np.testing.assert_array_equal(masked, np.where(mag > thr, ph, np.float32(0)))       # device-side threshold == host rule
     assert float(b.outs["dpca_mag"].download(np.float32, (8, n)).max()) > 0             # channels differ
+    b.use_lane(0)
     for f in (0, 1, 17, 40, 63):
         np.testing.assert_array_equal(st[f], _independent_slot(sarx, ctx, n, f, "multilook"))
     # frame order: every slot is its own frame (noise frames have distinct multilooked images)
@@ -192,6 +196,29 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def test_frames_in_flight_do_not_change_the_stack():
+    """Frame i of a rank runs on compute lane i % lanes with that lane's own plan and buffers (sarx_select_lane): one, two or
+    three frames in flight give the same product stack bit for bit, and so does the global maximum."""
+    import sarx
+    from sarx.batch import TwoChannelBatch
+    ctx = sarx.default_context()
+    n, frames = 1024, 7
+    ref = gref = None
+    for lanes in (1, 2, 3):
+        b = TwoChannelBatch(ctx, n, frames, stack="products", lanes=lanes)
+        assert b.lanes == lanes
+        b.run()
+        ctx.sync()
+        st, g = b.stack(), b.global_max()
+        b.close()
+        if ref is None:
+            ref, gref = st, g
+            assert np.isfinite(st).all() and g == float(np.abs(st).max())
+        else:
+            np.testing.assert_array_equal(st, ref)
+            assert g == gref
 
 
 @pytest.mark.parametrize("stack,n,frames", [("multilook", 2048, 5), ("magnitude", 1024, 4)])

@@ -533,6 +533,39 @@ def test_longest_lines_each_pass(sx, ctx, n_az, n_rg):
     plan.close()
 
 
+def test_lanes_and_range_cu_share_leave_results_unchanged(sx, ctx):
+    """sarx_select_lane / sarx_set_range_cus: a focus enqueued on lane 1, with the persistent 16384-sample range launch sized for
+    64 of the CUs, while another frame runs on lane 0, equals the focus on lane 0 with the whole chip bit for bit; sarx_sync waits
+    for every lane; a lane out of range is refused."""
+    from sarx import _ffi
+    n_az, n_rg = 256, 16384
+    raw, k = orc.point_scene(n_az, n_rg, seed=21, n_targets=3)
+    args = orc.focus_args(k)
+    p0, p1 = _plan(sx, ctx, n_az, n_rg, args, flags=_ffi.FUSE_RANGE), sx.CsaPlan(ctx, n_az, n_rg, *args, flags=_ffi.FUSE_RANGE)
+    d_in, a0, a1, b1 = ctx.to_device(raw), ctx.alloc(raw.nbytes), ctx.alloc(raw.nbytes), ctx.alloc(raw.nbytes)
+    p0.focus_dev(d_in, a0)
+    ctx.sync()
+    ref = a0.download(np.complex64, raw.shape)
+    ctx.set_range_cus(64)
+    for _ in range(3):                                   # two frames in flight, alternating lanes
+        ctx.select_lane(0)
+        p0.focus_dev(d_in, a1)
+        ctx.select_lane(1)
+        p1.focus_dev(d_in, b1)
+    ctx.select_lane(0)
+    ctx.set_range_cus(0)
+    ctx.lanes_join()
+    ctx.sync()
+    np.testing.assert_array_equal(a1.download(np.complex64, raw.shape), ref)
+    np.testing.assert_array_equal(b1.download(np.complex64, raw.shape), ref)
+    with pytest.raises(sx.SarxError):
+        ctx.select_lane(4)
+    p0.close()
+    p1.close()
+    for b in (d_in, a0, a1, b1):
+        b.release()
+
+
 def test_rccl_allgather_single_rank(sx, ctx):
     """The RCCL path end to end on one GPU: communicator of one rank, gather = copy, on the comm stream."""
     from sarx.batch import RcclStackComm
