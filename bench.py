@@ -463,18 +463,20 @@ def main():
 
     # HBM bytes per launch: PMC counters cannot be read inside this process; the figure is REPLAYED from the separate
     # rocprofv3 --pmc passes kept under profiles/ (tools/pmc_traffic.sh), and labelled as such
-    traffic, traffic_src, traffic_p2 = None, None, None
-    for name in ("r03_pmc_range_kernels.json", "r02_pmc_range_kernels.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                pmc = json.load(fh)
-            if n == 16384 and not a.unfused:
-                traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "range_fused" in k)
-                traffic_src = f"replayed from profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), not measured in this run"
-                traffic_p2 = next((v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "range_wp_kernel<2>" in k), None)
-                break
-        except (OSError, StopIteration, KeyError, ValueError):
-            continue
+    def replay(kernel_substr):
+        for name in ("r04_pmc_range_kernels.json", "r03_pmc_range_kernels.json", "r02_pmc_range_kernels.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    pmc = json.load(fh)
+                val = next(v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if kernel_substr in k)
+                return val, f"replayed from profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), not measured in this run"
+            except (OSError, StopIteration, KeyError, ValueError):
+                continue
+        return None, None
+    traffic, traffic_src, traffic_p2, traffic_p2_src = None, None, None, None
+    if n == 16384 and not a.unfused:
+        traffic, traffic_src = replay("range_fused")
+        traffic_p2, traffic_p2_src = replay("range_wp_kernel<2>")
 
     line = None
     if rank == 0:
@@ -496,6 +498,13 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": rg_ms / launches,
                          "algorithmic_bytes_per_launch": 16.0 * n * n},
         }
+        moved = (5 if (n > 128 and not a.unfused) else 6 if n > 128 else 3 if not a.unfused else 4) * 16.0 * n * n   # HBM round trips of the image per frame
+        line["frame_bandwidth"] = {
+            "algorithmic_bytes_per_frame": 64.0 * n * n, "moved_bytes_per_frame": moved,
+            "achieved_GBps_algorithmic": 64.0 * n * n * world / (dt / K) / 1e9 / world, "achieved_GBps_moved": moved / (dt / K) / 1e9,
+            "frac_of_peak_algorithmic": 64.0 * n * n / (dt / K) / 1e9 / HBM_PEAK_GBS, "frac_of_peak_moved": moved / (dt / K) / 1e9 / HBM_PEAK_GBS,
+            "note": "whole frame per GPU over the timed region: SURVEY.md 8(d)'s four passes x 16 B/sample (algorithmic) and the image's actual HBM "
+                    "round trips (two launches per two-step azimuth transform + the fused range launch)"}
         line["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SARX_")}      # kernel-form switches in effect
         if solo is not None:
             line["roofline"]["note"] = (f"measured live in the timed region, where {L} frames are in flight: launches of neighbouring frames share "
@@ -523,7 +532,7 @@ def main():
                 "bound": "hbm", "kernel": "range_wp_kernel<FFT+Phi2> (spectrum stored in the permuted order its inverse reads)" if perm
                 else "range pass FFT+Phi2", "achieved": p2["GBps_per_launch"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": p2["GBps_per_launch"] / HBM_PEAK_GBS, "launch_ms": p2["ms"], "launch_ms_rounds": p2["ms_rounds"],
-                "traffic": traffic_p2 if perm else None, "traffic_source": traffic_src if (perm and traffic_p2) else None,
+                "traffic": traffic_p2 if perm else None, "traffic_source": traffic_p2_src if (perm and traffic_p2) else None,
                 "algorithmic_bytes_per_launch": 16.0 * n * n,
                 "note": "the fused range-FFT + chirp-scaling-phase launch north_star's 70 % target names, as the unfused focus runs it: in place, "
                         "alternating with its inverse, HIP events around every launch on the ctx stream, three rounds of 10 launches, median "

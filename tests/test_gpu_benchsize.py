@@ -270,7 +270,9 @@ def test_8192_two_channel_point_targets_vs_oracle(sx, ctx):
     d = np.angle(np.exp(1j * (res["ati_phase_masked"][inside].astype(np.float64) - ref["ati_phase"][inside])))
     assert np.linalg.norm(d) / max(np.linalg.norm(ref["ati_phase"][inside]), 1e-30) < TOL
     assert orc.rel_l2(res["slc1_mag"], ref["slc1_mag"]) < TOL
-    assert orc.rel_l2(res["dpca_mag"][m], ref["dpca_mag"][m]) < 1e-3          # difference of nearly equal images
+    assert orc.rel_l2(res["dpca_mag"][m], ref["dpca_mag"][m]) < 1e-3          # difference of nearly equal images: relative to ITSELF ...
+    # ... and the same error measured against the images it is the difference of: the 1e-4 bar of every other plane
+    assert np.linalg.norm(res["dpca_mag"].astype(np.float64) - ref["dpca_mag"]) < 1e-4 * np.linalg.norm(ref["slc1_mag"])
     assert (res["ati_phase_masked"][~m & (res["slc1_mag"] < 0.049 * ref["max_mag"])] == 0).all()
     assert abs(res["max_mag"] - ref["max_mag"]) < 1e-5 * ref["max_mag"]
     # physics: the radial mover shows an ATI phase the stationary grid does not
