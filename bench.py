@@ -507,14 +507,20 @@ def main():
                     "round trips (two launches per two-step azimuth transform + the fused range launch)"}
         line["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SARX_")}      # kernel-form switches in effect
         if solo is not None:
-            line["roofline"]["note"] = (f"measured live in the timed region, where {L} frames are in flight: launches of neighbouring frames share "
-                                        "the GPU, so this launch's own duration stretches while the frame rate rises; roofline_solo is the same "
-                                        "launch with the GPU to itself")
+            # The roofline describes the KERNEL: it is taken from the one-frame-in-flight leg, where the launch has the GPU to itself and
+            # an event pair around it measures its execution (and agrees with rocprofv3 --kernel-trace of `bench.py --in-flight 1`).
+            # In the headline region launches of two frames share the GPU: an event pair around one of them also contains the time its
+            # workgroups wait for CUs the other frame's launches hold, which is not a property of the kernel - kept as roofline_shared.
+            shared = dict(line["roofline"])
+            shared["note"] = (f"HIP events around the range launch of every step of the HEADLINE region, {L} frames in flight: queueing behind and "
+                              "sharing with the other frame's launches included (rocprofv3 of the default command sees 1.3-1.4 ms of execution)")
+            line["roofline"].update(achieved=solo["range_achieved_GBps"], frac=solo["range_achieved_GBps"] / HBM_PEAK_GBS,
+                                    launch_ms=solo["range_launch_ms"], measured_in="the one_frame_in_flight leg of this run (lane 0 only, "
+                                    f"{solo['steps']} steps between barriers): HIP events around every range launch, the kernel alone on the GPU; "
+                                    "rocprofv3 summary of the same: profiles/r04_j_bench_inflight1_kernel_stats.csv (bench.py --in-flight 1)")
+            line["roofline_shared"] = shared
             line["one_frame_in_flight"] = {"ms_per_step": solo["ms_per_step"], "value": solo["value"], "unit": "frames/s", "steps": solo["steps"],
                                            "note": "the same steps on lane 0 only, timed after the headline region: one frame's latency"}
-            line["roofline_solo"] = dict(line["roofline"], achieved=solo["range_achieved_GBps"], frac=solo["range_achieved_GBps"] / HBM_PEAK_GBS,
-                                         launch_ms=solo["range_launch_ms"],
-                                         note="one frame in flight: HIP events around the range launch of every step of the one_frame_in_flight region")
         if collective:
             line["collective"] = {"transport": collective, "ranks": world, "rccl": rccl}
             # false = RCCL did not come up on every rank and the slots travelled through host memory (a rehearsal on fewer devices

@@ -325,7 +325,8 @@ using Mix13200P = MixCfg<13200, 24, 22, 25, 640, 0, 8, 25, 19, 24, true>;
 // convolution then fall on the 6000 samples either side of the window that 'same' discards - and of the lengths whose
 // line fits LDS (<= 20480) 27^3 is the one whose three stages all have <= 768 butterflies (729): twelve waves, three per
 // SIMD, 168 VGPRs.  (19200 = 32 * 24 * 25 needs 800 butterflies in one stage: thirteen waves, four on one SIMD, 128 VGPRs,
-// and spilled 32 of them.)
+// and spilled 32 of them.  Round 4: the re / im-plane form of 27^3 for two workgroups per CU - MixCfg<19683, 27, 27, 27, 768, 0, 2, 0, 2, 27, true>,
+// 77 KiB image, 80 VGPRs - spills 224 B per lane and takes the RDA focus from 2.13 to 3.02 ms: profiles/r04_n_rda_planes_and_lanes.log.)
 using Mix19683 = MixCfg<19683, 27, 27, 27, 768, 0, 2, 0, 2, 19>;     // 19 of the 27 rows prefetched: every row a 13200-sample line has samples in (27 rows spill at 168 VGPRs)
 
 template <class C, int MODE> static hipError_t launch_mixed(const RangeArgs& a, int cus, hipStream_t st) {

@@ -934,6 +934,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     return SARX_OK;
 }
 
+
 int sarx_csa_focus_host_c128(sarx_plan* p, const void* phist_host, void* image_host) {
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
     sarx_ctx* c = p->ctx;

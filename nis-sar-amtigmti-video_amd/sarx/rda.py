@@ -103,8 +103,8 @@ def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     else:
         if device_output:
             raise ValueError("device_output needs a device input (DeviceArray .T)")
-        mag = np.empty((n_p, n_r), dtype=np.float32)
-        stages = [np.empty((n_p, n_r), dtype=np.complex64) if intermediates else None for _ in range(3)]
+        mag = ctx.pinned_empty((n_p, n_r), np.float32)             # large results: page-locked pool (one DMA, no first touch)
+        stages = [ctx.pinned_empty((n_p, n_r), np.complex64) if intermediates else None for _ in range(3)]
         ptr = [s.ctypes.data if s is not None else None for s in stages]
         check(lib.sarx_rda_focus_host(plan.h, x.ctypes.data, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
     r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
