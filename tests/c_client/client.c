@@ -39,6 +39,32 @@ int main(int argc, char** argv) {
     const int rc = sarx_csa_plan_create(ctx, 1, n_rg, &prm, 0, &bad);
     printf("bad_plan_rc %d msg \"%s\"\n", rc, sarx_last_error(ctx));
 
+    /* round 4: the same image again through the entry points a frame loop uses - a page-locked result buffer (sarx_host_alloc: the
+     * download is one DMA) and two frames in flight on two lanes, each lane with its own plan and device buffers */
+    {
+        void *pin = NULL, *d_in = NULL, *d_img[2] = {NULL, NULL};
+        sarx_plan* plan1 = NULL;
+        if (sarx_host_alloc(ctx, n * 8, &pin)) die(ctx, "host_alloc");
+        if (sarx_csa_plan_create(ctx, n_az, n_rg, &prm, SARX_FUSE_RANGE, &plan1)) die(ctx, "plan_create (lane 1)");
+        if (sarx_malloc(ctx, n * 8, &d_in) || sarx_malloc(ctx, n * 8, &d_img[0]) || sarx_malloc(ctx, n * 8, &d_img[1])) die(ctx, "malloc");
+        if (sarx_memcpy_h2d(ctx, d_in, in, n * 8)) die(ctx, "h2d");
+        if (sarx_set_range_cus(ctx, 192)) die(ctx, "set_range_cus");
+        for (int f = 0; f < 4; ++f) {
+            if (sarx_select_lane(ctx, f & 1)) die(ctx, "select_lane");
+            if (sarx_csa_focus_dev((f & 1) ? plan1 : plan, d_in, d_img[f & 1])) die(ctx, "focus_dev");
+        }
+        if (sarx_select_lane(ctx, 0) || sarx_set_range_cus(ctx, 0) || sarx_lanes_join(ctx) || sarx_sync(ctx)) die(ctx, "join");
+        int same = 1;
+        for (int k = 0; k < 2; ++k) {
+            if (sarx_memcpy_d2h(ctx, pin, d_img[k], n * 8)) die(ctx, "d2h");
+            same = same && memcmp(pin, out, n * 8) == 0;
+        }
+        printf("lanes_bit_identical %d lane_out_of_range_rc %d\n", same, sarx_select_lane(ctx, 9));
+        sarx_free(ctx, d_in); sarx_free(ctx, d_img[0]); sarx_free(ctx, d_img[1]);
+        sarx_csa_plan_destroy(plan1);
+        sarx_host_free(ctx, pin);
+    }
+
     /* range axis and cross-range axis as the reference returns them */
     double* rax = malloc(sizeof(double) * n_rg);
     double* cax = malloc(sizeof(double) * n_az);

@@ -35,6 +35,8 @@ def test_c_client_focus_matches_oracle(tmp_path):
     assert orc.rel_l2(img.T, ref) < 1e-4
     m = re.search(r"bad_plan_rc (-?\d+) msg \"(.*)\"", r.stdout)
     assert m and int(m.group(1)) < 0 and len(m.group(2)) > 5
+    m = re.search(r"lanes_bit_identical (\d) lane_out_of_range_rc (-?\d+)", r.stdout)      # two frames in flight, page-locked download
+    assert m and m.group(1) == "1" and int(m.group(2)) < 0
     m = re.search(r"range_axis (\S+) (\S+) cross_range (\S+) (\S+)", r.stdout)
     got = [float(x) for x in m.groups()]
     np.testing.assert_allclose(got, [rax[0], rax[-1], cax[0], cax[-1]], rtol=1e-9, atol=1e-6)
