@@ -517,7 +517,7 @@ def main():
             line["roofline"].update(achieved=solo["range_achieved_GBps"], frac=solo["range_achieved_GBps"] / HBM_PEAK_GBS,
                                     launch_ms=solo["range_launch_ms"], measured_in="the one_frame_in_flight leg of this run (lane 0 only, "
                                     f"{solo['steps']} steps between barriers): HIP events around every range launch, the kernel alone on the GPU; "
-                                    "rocprofv3 summary of the same: profiles/r04_j_bench_inflight1_kernel_stats.csv (bench.py --in-flight 1)")
+                                    "rocprofv3 summary of the same: profiles/r04_p_bench_inflight1_kernel_stats.csv (bench.py --in-flight 1)")
             line["roofline_shared"] = shared
             line["one_frame_in_flight"] = {"ms_per_step": solo["ms_per_step"], "value": solo["value"], "unit": "frames/s", "steps": solo["steps"],
                                            "note": "the same steps on lane 0 only, timed after the headline region: one frame's latency"}
