@@ -311,6 +311,8 @@ __global__ __launch_bounds__(C::T) void range_mixed_kernel(RangeArgs a) {
 }
 // two workgroups per CU (MixCfg::PLANES): ten or twelve waves each, so a SIMD can be asked for six: 80 VGPRs
 template <class C, int MODE>
+// (five per SIMD = 96 VGPRs, no scratch, would do for the 20 waves of two workgroups only if they spread 5/5/5/5; they sit 6/6/4/4, one
+//  workgroup is left per CU and the launch takes 0.73 instead of 0.58 ms: profiles/r04_q_mixed_planes_waves5.log)
 __global__ __launch_bounds__(C::T) __attribute__((amdgpu_waves_per_eu(6, 6))) void range_mixed_planes_kernel(RangeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     range_mixed_body<C, MODE>(a, smem_raw);

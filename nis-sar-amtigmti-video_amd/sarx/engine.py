@@ -141,7 +141,7 @@ class Context:
         self._pinned_free = {}         # nbytes -> [ptr, ...]
         self._pinned_total = 0         # bytes handed out + bytes kept free
         self._pinned_cap = int(float(os.environ.get("SARX_PINNED_POOL_GIB", "16")) * 2 ** 30)
-        self._pinned_lock = threading.Lock()
+        self._pinned_lock = threading.RLock()         # re-entrant: a block may be finalised (GC) inside pinned_empty on the same thread
 
     def close(self):
         if self.h is not None:

@@ -566,6 +566,57 @@ def test_lanes_and_range_cu_share_leave_results_unchanged(sx, ctx):
         b.release()
 
 
+def test_lanes_with_different_plan_kinds_in_flight(sx, ctx):
+    """Four lanes, a different kind of plan on each - power-of-two fused, power-of-two unfused with the RG-major corner turn, a
+    chirp-z (any-size) plan, and a two-channel product stage - enqueued round-robin without any host synchronisation: every
+    result equals its one-lane result bit for bit (per-plan scratch and per-lane reduction scratch never collide)."""
+    from sarx import _ffi
+    jobs = []
+    for n_az, n_rg, flags, seed in [(512, 1024, _ffi.FUSE_RANGE, 1), (256, 512, _ffi.OUT_RG_MAJOR, 2), (96, 80, _ffi.FUSE_RANGE, 3)]:
+        raw, k = orc.point_scene(n_az, n_rg, seed=seed, n_targets=3)
+        plan = sx.CsaPlan(ctx, n_az, n_rg, *orc.focus_args(k), flags=flags)
+        jobs.append({"plan": plan, "in": ctx.to_device(raw), "out": ctx.alloc(raw.nbytes), "shape": raw.shape})
+    (r1, r2), k = orc.point_scene(256, 1024, seed=4, clutter_db=-20.0, two_channel=True)
+    p2 = sx.CsaPlan(ctx, 256, 1024, *orc.focus_args(k), flags=_ffi.FUSE_RANGE)
+    tc = {"d1": ctx.to_device(r1), "d2": ctx.to_device(r2), "s1": ctx.alloc(r1.nbytes), "s2": ctx.alloc(r1.nbytes),
+          "d_max": ctx.alloc(_ffi.MAX_SLOT_BYTES), "planes": [ctx.alloc(r1.size * 4) for _ in range(3)]}
+
+    def two_channel():
+        p2.set_max_slot(tc["d_max"])
+        p2.focus_dev(tc["d1"], tc["s1"])
+        p2.set_max_slot(None)
+        p2.set_ati(tc["s1"], tc["d_max"], 0.05, 0.0, *tc["planes"])
+        p2.focus_dev(tc["d2"], tc["s2"])
+        p2.set_ati(None)
+
+    def fetch():
+        outs = [j["out"].download(np.complex64, (j["shape"][0] * j["shape"][1],)) for j in jobs]
+        return outs + [b.download(np.float32, r1.shape) for b in tc["planes"]], ctx.ati_stats()
+    for j in jobs:                                            # one lane, one after the other
+        j["plan"].focus_dev(j["in"], j["out"])
+    two_channel()
+    ctx.sync()
+    ref, ref_stats = fetch()
+    for j in jobs:
+        sx._ffi.check(ctx.lib.sarx_memset(ctx.h, j["out"].ptr, 0, j["shape"][0] * j["shape"][1] * 8), ctx.h)
+    for rep in range(3):                                      # four lanes, no host synchronisation in between
+        for lane, j in enumerate(jobs):
+            ctx.select_lane(lane)
+            j["plan"].focus_dev(j["in"], j["out"])
+        ctx.select_lane(3)
+        two_channel()
+    got, stats = fetch()                                      # downloads wait for every lane; ati_stats reads lane 3's scratch
+    ctx.select_lane(0)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    assert stats == ref_stats
+    for j in jobs:
+        j["plan"].close(); j["in"].release(); j["out"].release()
+    p2.close()
+    for b in (tc["d1"], tc["d2"], tc["s1"], tc["s2"], tc["d_max"], *tc["planes"]):
+        b.release()
+
+
 def test_rccl_allgather_single_rank(sx, ctx):
     """The RCCL path end to end on one GPU: communicator of one rank, gather = copy, on the comm stream."""
     from sarx.batch import RcclStackComm
