@@ -152,7 +152,8 @@ def test_products_stack_holds_every_frames_three_planes():
     b2.close()
 
 
-def test_c3_scene_frames_against_the_oracle():
+@pytest.mark.parametrize("n,scene_scale", [(2048, 0.25), (4096, 0.5)])
+def test_c3_scene_frames_against_the_oracle(n, scene_scale):
     """scene="c3" (frame f = the C3 scene - 5 x 5 grid, a 15 m/s radial mover, a slow mover - with the
     movers advanced by f * 0.1 s): the echoes the driver synthesises on the device are downloaded and focused by the
     oracle in complex128; the frame's three planes in the product stack are held to the oracle's, and the radial mover's
@@ -161,8 +162,8 @@ def test_c3_scene_frames_against_the_oracle():
     from oracle import csa_oracle as orc
     from sarx.batch import TwoChannelBatch
     ctx = sarx.default_context()
-    n, frames = 2048, 3
-    b = TwoChannelBatch(ctx, n, frames, stack="products", scene="c3", scene_scale=0.25)
+    frames = 3
+    b = TwoChannelBatch(ctx, n, frames, stack="products", scene="c3", scene_scale=scene_scale)
     b.run()
     ctx.sync()
     st = b.stack()

@@ -220,6 +220,46 @@ def test_full_scene_sampled_rows_and_columns(sx, ctx, n):
     plan_u.close()
 
 
+# ---- (b2) the form bench.py times since round 4: two 16384^2 frames in flight on two lanes, range launch on 192 CUs ----
+def test_two_frames_in_flight_at_bench_size_equal_one_at_a_time(sx, ctx):
+    """Frame A on lane 0 and frame B on lane 1, alternating without host synchronisation and with the persistent range launch sized
+    for 192 of the CUs (bench.py's default timed region), leave exactly the images the same plans produce one frame at a time with
+    the whole chip: compared on the device over all 2^28 samples (energy of the difference = 0) and on downloaded rows."""
+    from sarx import _ffi, radar
+    n = 16384
+    px = n * n
+    args = radar.focus_args(n)
+    plans = [sx.CsaPlan(ctx, n, n, *args, flags=_ffi.FUSE_RANGE) for _ in range(2)]
+    xs = [ctx.alloc(px * 8) for _ in range(2)]
+    refs = [ctx.alloc(px * 8) for _ in range(2)]
+    outs = [ctx.alloc(px * 8) for _ in range(2)]
+    diff = ctx.alloc(px * 8)
+    for i in range(2):
+        ctx.fill_noise(xs[i], px, 77 + i)
+        plans[i].focus_dev(xs[i], refs[i])                    # one at a time, lane 0, all CUs
+    ctx.sync()
+    ctx.set_range_cus(192)
+    for f in range(6):
+        ctx.select_lane(f & 1)
+        plans[f & 1].focus_dev(xs[f & 1], outs[f & 1])
+    ctx.select_lane(0)
+    ctx.set_range_cus(0)
+    ctx.lanes_join()
+    planes = {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")}
+    scratch = dict(planes)
+    planes["dpca_diff"] = diff
+    rows = [0, 1, 255, 256, 8191, 8192, 16383]
+    for i in range(2):
+        ctx.ati_dpca(outs[i], refs[i], px, 0.0, planes, want_stats=False)
+        assert _energy(ctx, diff, px, scratch) == 0.0
+        assert _energy(ctx, outs[i], px, scratch) > 0
+        np.testing.assert_array_equal(_download_rows(ctx, outs[i], n, rows), _download_rows(ctx, refs[i], n, rows))
+    for b in (*xs, *refs, *outs, diff, *scratch.values()):
+        b.release()
+    for p in plans:
+        p.close()
+
+
 # ---- (c) two different channels at 8192^2 ---------------------------------------------------------------------------
 def test_8192_two_channel_point_targets_vs_oracle(sx, ctx):
     """BASELINE config 3 with real content: a 5 x 5 grid of stationary scatterers, a 15 m/s radial mover and a slow
