@@ -43,9 +43,11 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=16384)
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=None,
                     help="frames in flight per GPU: consecutive (independent) frames are enqueued on this many alternating compute lanes of the "
-                         "context, each lane with its own plan and buffers, so kernels of neighbouring frames overlap (1 = one frame at a time)")
+                         "context, each lane with its own plan and buffers, so kernels of neighbouring frames overlap (1 = one frame at a time; "
+                         "default: 2 for frames of 4096^2 and more, 1 below - small frames are launch-bound and lose to the lane switches)")
+    ap.add_argument("--batch-lanes", type=int, default=None, help="frames in flight of the batch64 block (default: the batch driver's own rule)")
     ap.add_argument("--range-cus", type=int, default=None,
                     help="compute units the persistent range launch sizes its grid for while frames are in flight (default 192 of 256; 0 = all)")
     ap.add_argument("--unfused", action="store_true", help="run range passes 2 and 3 as two launches")
@@ -182,7 +184,7 @@ def run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, s
     """BASELINE config 5 through the shared device driver; returns the block for the JSON line (rank 0) or None."""
     from sarx.batch import TwoChannelBatch
     b = TwoChannelBatch(ctx, a.batch_size, a.batch_frames, world, rank, stack=stack, looks=LOOKS, rccl=use_rccl and world > 1,
-                        host_comm=None if (use_rccl or world == 1) else host_comm, scene=a.batch_scene, lanes=a.in_flight)
+                        host_comm=None if (use_rccl or world == 1) else host_comm, scene=a.batch_scene, lanes=a.batch_lanes)
     b.prepare()                                                  # echoes of this rank's frames resident in HBM before the clock
     b.run()                                                      # warm-up batch
     times = []
@@ -295,6 +297,8 @@ def main():
     # Frames are independent (sar_batch_sim.py:303-331): frame s runs on lane s % L of the context, every lane with its own plan
     # (scratch), its own echo and its own image, so the launches of neighbouring frames share the GPU - the issue-bound range launch
     # of one frame beside the bandwidth-bound azimuth launches of the next.  Every step is still one whole focus of one frame.
+    if a.in_flight is None:
+        a.in_flight = 2 if n >= 4096 else 1
     L = max(1, min(a.in_flight, 4))
     range_cus = a.range_cus if a.range_cus is not None else (192 if L > 1 else 0)
     plans = [sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=flags) for _ in range(L)]

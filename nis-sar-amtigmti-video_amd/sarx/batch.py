@@ -218,7 +218,7 @@ class TwoChannelBatch:
 
     def __init__(self, ctx, n, n_frames, world=1, rank=0, stack="multilook", looks=16, rccl=False, host_comm=None,
                  seed_base=1000, flags=None, mask_frac=0.05, resident=True, fused_mask=True, fused_ati=True, scene="noise",
-                 scene_scale=1.0, lanes=2):
+                 scene_scale=1.0, lanes=None):
         from . import _ffi, radar
         from .engine import CsaPlan
         if stack not in STACKS:
@@ -244,6 +244,8 @@ class TwoChannelBatch:
         # Frames in flight: this rank's i-th frame runs on compute lane i % lanes of the context (sarx_select_lane), every lane
         # with its own plan (scratch), image buffers and product planes, so the launches of consecutive frames overlap on the GPU.
         # Results do not depend on it (same kernels, separate buffers).
+        if lanes is None:                   # frames of 4096^2 and more gain 3-8 %; small frames are launch-bound and lose to the lane switches
+            lanes = 2 if n >= 4096 else 1
         self.lanes = max(1, min(int(lanes), 4))
         self.range_cus = 192                # of 256: sarx_set_range_cus while frames are in flight (only the persistent 16384-sample launch looks at it)
         self._lane_state = []

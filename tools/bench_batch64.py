@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--stack", choices=("multilook", "magnitude", "products"), default="multilook")
     ap.add_argument("--scene", choices=("noise", "c3"), default="noise", help="c3: SURVEY.md 8(d) C5's content, movers advanced by f * 0.1 s per frame")
-    ap.add_argument("--lanes", type=int, default=2, help="frames in flight (compute lanes of the context)")
+    ap.add_argument("--lanes", type=int, default=None, help="frames in flight (compute lanes of the context)")
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     import sarx
