@@ -422,6 +422,49 @@ class CsaPlan:
         check(self.ctx.lib.sarx_csa_pass(self.h, int(pass_id), d_in.ptr, d_out.ptr), self.ctx.h)
 
 
+class FocusLanes:
+    """A frame loop's focuser with frames in flight: consecutive focus_dev calls go to alternating compute lanes of the context,
+    each lane with its own CsaPlan (scratch), so the launches of neighbouring frames share the GPU (sarx_select_lane; DESIGN.md
+    4.8).  The caller gives every frame in flight its own input and output buffers; results equal CsaPlan.focus_dev bit for bit.
+
+        fl = sarx.FocusLanes(ctx, n_az, n_rg, *focus_args)            # frames are independent (sar_batch_sim.py:303-331)
+        for f in range(n_frames):
+            fl.focus_dev(d_echo[f], d_image[f])                        # only enqueues
+        fl.finish()                                                    # lane 0 selected again, every lane joined; ctx.sync() to wait
+
+    lanes=None: two for frames of 4096^2 samples and more, one below (small frames are launch-bound)."""
+
+    def __init__(self, ctx, n_az, n_rg, *focus_args, lanes=None, flags=_ffi.FUSE_RANGE, range_cus=192):
+        if lanes is None:
+            lanes = 2 if int(n_az) * int(n_rg) >= 4096 * 4096 else 1
+        self.ctx, self.lanes, self.range_cus = ctx, max(1, min(int(lanes), 4)), int(range_cus)
+        self.plans = [CsaPlan(ctx, n_az, n_rg, *focus_args, flags=flags) for _ in range(self.lanes)]
+        self._i = 0
+
+    def focus_dev(self, d_phist, d_image):
+        lane = self._i % self.lanes
+        self._i += 1
+        if self.lanes > 1:
+            self.ctx.select_lane(lane)
+            self.ctx.set_range_cus(self.range_cus)     # the persistent range launch leaves CUs to the other lane's azimuth tiles
+        self.plans[lane].focus_dev(d_phist, d_image)
+        return lane
+
+    def finish(self):
+        """Back to lane 0 with every lane joined (device-side): whatever is enqueued next sees all frames finished."""
+        if self.lanes > 1:
+            self.ctx.select_lane(0)
+            self.ctx.set_range_cus(0)
+            self.ctx.lanes_join()
+        self._i = 0
+
+    def close(self):
+        self.finish()
+        for p in self.plans:
+            p.close()
+        self.plans = []
+
+
 _default_ctx = {}
 
 

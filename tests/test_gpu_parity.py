@@ -566,6 +566,32 @@ def test_lanes_and_range_cu_share_leave_results_unchanged(sx, ctx):
         b.release()
 
 
+def test_focus_lanes_helper(sx, ctx):
+    """sarx.FocusLanes: a frame loop with two frames in flight returns every frame's image bit-identical to CsaPlan.focus_dev,
+    alternates lanes, and leaves lane 0 selected with the range launch's CU share reset after finish()."""
+    n_az, n_rg = 4096, 4096
+    raws, k = [], None
+    for seed in (1, 2, 3):
+        raw, k = orc.point_scene(n_az, n_rg, seed=seed, n_targets=3)
+        raws.append(raw)
+    args = orc.focus_args(k)
+    plan = sx.CsaPlan(ctx, n_az, n_rg, *args, flags=sx._ffi.FUSE_RANGE)
+    d_in = [ctx.to_device(r) for r in raws]
+    d_ref, d_out = ctx.alloc(raws[0].nbytes), [ctx.alloc(raws[0].nbytes) for _ in raws]
+    fl = sx.FocusLanes(ctx, n_az, n_rg, *args)
+    assert fl.lanes == 2 and sx.FocusLanes(ctx, 256, 256, *args).lanes == 1
+    used = [fl.focus_dev(d_in[i], d_out[i]) for i in range(3)]
+    fl.finish()
+    assert used == [0, 1, 0]
+    for i in range(3):
+        plan.focus_dev(d_in[i], d_ref)
+        np.testing.assert_array_equal(d_out[i].download(np.complex64, raws[i].shape), d_ref.download(np.complex64, raws[i].shape))
+    fl.close()
+    plan.close()
+    for b in (*d_in, d_ref, *d_out):
+        b.release()
+
+
 def test_lanes_with_different_plan_kinds_in_flight(sx, ctx):
     """Four lanes, a different kind of plan on each - power-of-two fused, power-of-two unfused with the RG-major corner turn, a
     chirp-z (any-size) plan, and a two-channel product stage - enqueued round-robin without any host synchronisation: every
