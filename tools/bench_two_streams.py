@@ -62,7 +62,7 @@ def run(mode, ctxs, plans, bufs, k):
 for mode in modes:
     ctxs, plans, bufs = setup(mode)
     for rep in range(2):
-        for k in (1, 2, 3, 1):
+        for k in [int(x) for x in os.environ.get("TWO_STREAMS_K", "1,2,3,1").split(",")]:
             ms = run(mode, ctxs, plans, bufs, k)
             print(f"{n}x{n} [{mode:5s}]: {k} frame(s) in flight  {ms:.3f} ms per frame  {1e3 / ms:.1f} frames/s", flush=True)
     for p in plans:
