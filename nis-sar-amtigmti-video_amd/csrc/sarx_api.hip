@@ -96,10 +96,6 @@ struct sarx_ctx {
     hipEvent_t lane_ev[LANES] = {};
     int cur_lane = 0;
     hipStream_t comm_stream = nullptr;
-    static constexpr int SLAB_STREAMS = 8;
-    hipStream_t slab_stream[SLAB_STREAMS] = {};   // slab mode with SARX_SLAB_STREAMS > 1: independent tile groups on concurrent streams
-    hipEvent_t slab_ev[SLAB_STREAMS] = {};
-    hipEvent_t slab_fork = nullptr;
     hipEvent_t ev[N_EVENTS] = {};
     bool ev_set[N_EVENTS] = {};
     hipEvent_t comm_fence = nullptr;
@@ -145,7 +141,6 @@ struct sarx_plan {
     float* max_slot = nullptr;         // sarx_csa_plan_set_max_slot: device float that receives max |image| of every focus
     bool az_nt = false;    // azimuth tile launches use nontemporal accesses (images >= 512 MiB; SARX_AZ_NT=0/1 overrides)
     int slab_tiles = 0;    // > 0: slab mode of sarx_csa_focus_dev with this many azimuth tiles per group (SARX_SLAB_MIB)
-    int slab_streams = 1;  // SARX_SLAB_STREAMS: the groups' three-launch chains round-robin over this many streams
     double2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr;
     float2* buf_b = nullptr;           // scratch image
     float2* buf_a = nullptr;           // second scratch (RG_MAJOR only)
@@ -335,11 +330,6 @@ int sarx_destroy(sarx_ctx* c) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
         if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
     }
-    for (int k = 0; k < sarx_ctx::SLAB_STREAMS; ++k) {
-        if (c->slab_stream[k]) hipStreamDestroy(c->slab_stream[k]);
-        if (c->slab_ev[k]) hipEventDestroy(c->slab_ev[k]);
-    }
-    if (c->slab_fork) hipEventDestroy(c->slab_fork);
     for (int k = 0; k < sarx_ctx::LANES; ++k) {
         if (c->lane_ev[k]) hipEventDestroy(c->lane_ev[k]);
         if (k > 0 && c->lane[k]) hipStreamDestroy(c->lane[k]);
@@ -505,10 +495,6 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
             if (q < 1) q = 1;
             if (q > n_az / p->az_s) q = n_az / p->az_s;
             p->slab_tiles = q;
-        }
-        if (const char* e3 = getenv("SARX_SLAB_STREAMS")) {
-            const int k = atoi(e3);
-            if (k >= 1 && k <= sarx_ctx::SLAB_STREAMS) p->slab_streams = k;
         }
     }
     if (const char* e = getenv("SARX_AZ_W")) { const int w = atoi(e); if ((w == 16 || w == 32 || w == 64) && n_rg % w == 0) p->az_w = w; }
@@ -866,23 +852,8 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
         float2* last = rg_major ? p->buf_a : (float2*)d_image;
         if ((rc = az_step(p, false, false, S, d_phist, d_image, 0, S)) != SARX_OK) return rc;       // forward step A, whole image
         bool marked = false;
-        // The groups are independent of each other between the two whole-image launches, so their chains may run on several
-        // streams at once: a group's 128-line range launch leaves half the CUs to the neighbouring groups' tile launches.
-        const int NS = p->slab_streams;
-        struct StreamGuard { sarx_ctx* c; hipStream_t main; ~StreamGuard() { c->stream = main; } } guard{c, c->stream};
-        if (NS > 1) {
-            if (!c->slab_fork) HIPCHK(c, hipEventCreateWithFlags(&c->slab_fork, hipEventDisableTiming));
-            for (int k = 0; k < NS; ++k) {
-                if (!c->slab_stream[k]) HIPCHK(c, hipStreamCreateWithFlags(&c->slab_stream[k], hipStreamNonBlocking));
-                if (!c->slab_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->slab_ev[k], hipEventDisableTiming));
-            }
-            HIPCHK(c, hipEventRecord(c->slab_fork, guard.main));
-            for (int k = 0; k < NS; ++k) HIPCHK(c, hipStreamWaitEvent(c->slab_stream[k], c->slab_fork, 0));
-        }
-        int gi = 0;
-        for (int q0 = 0; q0 < RA; q0 += Q, ++gi) {
+        for (int q0 = 0; q0 < RA; q0 += Q) {
             const int nq = (q0 + Q <= RA) ? Q : RA - q0;
-            if (NS > 1) c->stream = c->slab_stream[gi % NS];
             if ((rc = az_step(p, false, true, S, d_image, p->buf_b, q0, nq)) != SARX_OK) return rc;
             RangeArgs a = range_args(p, p->buf_b, p->buf_b);
             a.n_az = nq * S; a.row0 = q0; a.row_inner = nq; a.row_stride = RA;
@@ -892,12 +863,6 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
             if (mark && p->mark_stop >= 0) { HIPCHK(c, hipEventRecord(c->ev[p->mark_stop], c->stream)); c->ev_set[p->mark_stop] = true; marked = true; }
             if ((rc = az_step(p, true, false, RA, p->buf_b, p->buf_b, q0, nq)) != SARX_OK) return rc;   // inverse step A, stride RA
         }
-        c->stream = guard.main;
-        if (NS > 1)
-            for (int k = 0; k < NS; ++k) {
-                HIPCHK(c, hipEventRecord(c->slab_ev[k], c->slab_stream[k]));
-                HIPCHK(c, hipStreamWaitEvent(guard.main, c->slab_ev[k], 0));
-            }
         if ((rc = az_step(p, true, true, RA, p->buf_b, last, 0, S)) != SARX_OK) return rc;           // inverse step B, whole image
         if ((rc = look_finish(p)) != SARX_OK) return rc;
         if (rg_major) HIPCHK(c, launch_corner_turn(p->buf_a, (float2*)d_image, p->n_az, p->n_rg, c->stream));
