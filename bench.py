@@ -273,7 +273,8 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if a.dry_run:                                                # launcher / rendezvous check, no GPU needed
-        me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid()}
+        me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(),
+              "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         ranks = [me]
         if dist is not None:
             ranks = [None] * world

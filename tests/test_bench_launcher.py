@@ -50,3 +50,29 @@ def test_child_failure_propagates():
     """A rank that fails (here: an unknown flag) makes the launcher exit non-zero."""
     r = _run(["--gpus", "2", "--dry-run", "--no-such-flag"])
     assert r.returncode != 0
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_driver_style_launch_of_eight_ranks_sets_the_ipc_mode_itself():
+    """The other documented launch - `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`, the way the driver
+    starts the 8-GPU scaling run - with HSA_ENABLE_IPC_MODE_LEGACY absent from the environment: every rank sets it to 0 at its own
+    start (RCCL across processes needs dmabuf IPC on this pool), before anything could touch a GPU; one JSON line, eight ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "8", "--dry-run"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["dry_run"] and line["n_gpus"] == 8 and sorted(x["rank"] for x in line["ranks"]) == list(range(8))
+    assert all(x["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for x in line["ranks"])
