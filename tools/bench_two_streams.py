@@ -50,6 +50,11 @@ def run(mode, ctxs, plans, bufs, k):
     for c in ctxs[:k]:
         c.sync()
     t0 = time.perf_counter()
+    nfill = int(os.environ.get("TWO_STREAMS_DELAY_FILLS", "0"))      # one-time head start for lane 0: lane 1 first fills a scratch image n times
+    if nfill and k > 1 and mode != "ctx":
+        ctxs[0].select_lane(1)
+        for _ in range(nfill):
+            ctxs[0].fill_noise(bufs[2][1], n * n, 5)
     for f in range(frames):
         frame(f)
     for c in ctxs[:k]:
