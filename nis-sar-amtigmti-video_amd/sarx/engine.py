@@ -129,6 +129,9 @@ class Context:
 
     PINNED_MIN_BYTES = 64 << 20        # smaller results are plain NumPy arrays (the library copies them with one hipMemcpy anyway)
     PINNED_FREE_PER_SIZE = 2           # free blocks kept per size; a caller that holds results alive gets fresh blocks
+    PINNED_FROM_REQUEST = 4            # a size earns page-locked blocks from its fourth request on: hipHostMalloc costs 0.15 s per GiB,
+                                       # up to 2.6 x the first touch of a pageable result, so a one-shot script (two images, three planes,
+                                       # three intermediate maps of one size at most) never pays it; a frame loop pays it twice
 
     def __init__(self, device_id=0):
         self.lib = _ffi.load()
@@ -139,6 +142,7 @@ class Context:
         self._live = {}
         self._plans = weakref.WeakSet()
         self._pinned_free = {}         # nbytes -> [ptr, ...]
+        self._pinned_seen = {}         # nbytes -> requests so far
         self._pinned_total = 0         # bytes handed out + bytes kept free
         self._pinned_cap = int(float(os.environ.get("SARX_PINNED_POOL_GIB", "16")) * 2 ** 30)
         self._pinned_lock = threading.RLock()         # re-entrant: a block may be finalised (GC) inside pinned_empty on the same thread
@@ -161,19 +165,21 @@ class Context:
     # -- pooled page-locked result arrays --
     def pinned_empty(self, shape, dtype):
         """np.empty(shape, dtype) on page-locked memory from a per-context pool (results of the *_host entry points): the
-        download is one DMA at the PCIe rate and a second call of the same size pays neither hipHostMalloc nor the first touch
+        download is one DMA at the PCIe rate and a repeated call of the same size pays neither hipHostMalloc nor the first touch
         of fresh pages.  The array is the caller's like any NumPy result; its block returns to the pool when the array and all
-        views of it are gone.  Small results, an exhausted pool budget (SARX_PINNED_POOL_GIB, default 16) or a failed pinned
-        allocation give an ordinary np.empty."""
+        views of it are gone.  Small results, the first three requests of a size (a one-shot script should not pay 0.15 s per GiB
+        of hipHostMalloc for arrays it downloads once), an exhausted pool budget (SARX_PINNED_POOL_GIB, default 16) or a failed
+        pinned allocation give an ordinary np.empty."""
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape)) * dtype.itemsize
         if nbytes < self.PINNED_MIN_BYTES or self.h is None:
             return np.empty(shape, dtype)
         with self._pinned_lock:
+            seen = self._pinned_seen[nbytes] = self._pinned_seen.get(nbytes, 0) + 1
             free = self._pinned_free.get(nbytes)
             ptr = free.pop() if free else None
             if ptr is None:
-                if self._pinned_total + nbytes > self._pinned_cap:
+                if seen < self.PINNED_FROM_REQUEST or self._pinned_total + nbytes > self._pinned_cap:
                     return np.empty(shape, dtype)
                 out = C.c_void_p()
                 if self.lib.sarx_host_alloc(self.h, nbytes, C.byref(out)) != 0 or not out.value:

@@ -218,19 +218,36 @@ def test_two_channel_end_to_end(sx):
         np.testing.assert_array_equal(lean[key], res[key])
 
 
-def test_host_call_results_come_from_a_page_locked_pool(sx, ctx):
+def test_host_call_results_come_from_a_page_locked_pool(sx):
     """sar_focus_csa(numpy) -> numpy, the call a maintainer makes (:410-411): results of 64 MiB and more sit on page-locked
     blocks of a per-context pool.  A result stays the caller's while it is alive (a second call gets another block), its block is
     reused once it is gone, `out=` overwrites an earlier result in place, and every variant returns the same image bit for bit."""
     raw, k = orc.point_scene(2048, 4096, seed=3, n_targets=3)            # 64 MiB image
     args = orc.focus_args(k)
-    a, ra, ca = sx.sar_focus_csa(raw, *args, ctx=ctx)
-    assert a.shape == (4096, 2048) and a.T.flags.c_contiguous
+    ctx = sx.Context(0)                                                  # its own context: the pool's request counts start at zero
+    from sarx.engine import _PinnedBlock
+
+    def root(x):
+        while getattr(x, "base", None) is not None:
+            x = x.base
+        return x
+    first, ra, ca = sx.sar_focus_csa(raw, *args, ctx=ctx)
+    second, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx)
+    third, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx)
+    assert first.shape == (4096, 2048) and first.T.flags.c_contiguous
+    # the first three requests of a size are ordinary arrays (a one-shot script never pays hipHostMalloc) ...
+    assert not any(isinstance(root(x), _PinnedBlock) for x in (first, second, third))
+    np.testing.assert_array_equal(first, second)
+    np.testing.assert_array_equal(first, third)
+    ref = first.copy()
+    del first, second, third
+    a, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx)                      # ... from the fourth on the size has page-locked blocks
+    assert isinstance(root(a), _PinnedBlock)
     addr_a = a.T.ctypes.data
     b, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx)                      # a is still alive: b must not alias it
     assert b.T.ctypes.data != addr_a
     np.testing.assert_array_equal(a, b)
-    ref = a.copy()
+    np.testing.assert_array_equal(a, ref)
     del a
     import gc
     gc.collect()
@@ -246,16 +263,13 @@ def test_host_call_results_come_from_a_page_locked_pool(sx, ctx):
         sx.sar_focus_csa(raw, *args, ctx=ctx, out=plain)                 # C-contiguous [n_rg x n_az] is the wrong layout for the view
     e, _, _ = sx.sar_focus_csa(raw, *args, ctx=ctx, out=np.zeros((2048, 4096), np.complex64).T)
     np.testing.assert_array_equal(e, ref)
-    from sarx.engine import _PinnedBlock
-
-    def root(x):
-        while getattr(x, "base", None) is not None:
-            x = x.base
-        return x
     assert isinstance(root(c), _PinnedBlock)
     small, ks = orc.point_scene(256, 256, seed=3, n_targets=3)
     s_img, _, _ = sx.sar_focus_csa(small, *orc.focus_args(ks), ctx=ctx)   # small results stay ordinary arrays
     assert not isinstance(root(s_img), _PinnedBlock)
+    del b, c, d, e, s_img
+    sx.clear_plan_cache()                                                # the facade's cached plans of this context
+    ctx.close()
 
 
 def test_two_channel_fallback_takes_the_threshold_from_channel_one(sx):
