@@ -106,6 +106,7 @@ struct sarx_ctx {
     float* ati_part_max_all = nullptr;     // reduction scratch, one set per lane (two frames in flight must not share it)
     double2* ati_part_sum_all = nullptr;
     double* ati_out3_all = nullptr;
+    double* power_part_all = nullptr;       // sarx_power_stats_dev partials, one set per lane (it used to hipMalloc / hipFree per call)
     float* ati_part_max_() const { return ati_part_max_all + (size_t)cur_lane * 4096; }
     double2* ati_part_sum_() const { return ati_part_sum_all + (size_t)cur_lane * 4096; }
     double* ati_out3_() const { return ati_out3_all + (size_t)cur_lane * 4; }
@@ -312,6 +313,7 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
     HIPCHK(nullptr, hipMalloc(&c->ati_part_max_all, sarx_ctx::LANES * 4096 * sizeof(float)));
     HIPCHK(nullptr, hipMalloc(&c->ati_part_sum_all, sarx_ctx::LANES * 4096 * sizeof(double2)));
     HIPCHK(nullptr, hipMalloc(&c->ati_out3_all, sarx_ctx::LANES * 4 * sizeof(double)));
+    HIPCHK(nullptr, hipMalloc(&c->power_part_all, sarx_ctx::LANES * 2048 * sizeof(double)));
     *out_ctx = c;
     return SARX_OK;
 }
@@ -321,7 +323,7 @@ int sarx_destroy(sarx_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    hipFree(c->tw_all); hipFree(c->ati_part_max_all); hipFree(c->ati_part_sum_all); hipFree(c->ati_out3_all);
+    hipFree(c->tw_all); hipFree(c->ati_part_max_all); hipFree(c->ati_part_sum_all); hipFree(c->ati_out3_all); hipFree(c->power_part_all);
     for (int i = 0; i < N_EVENTS; ++i) hipEventDestroy(c->ev[i]);
     hipEventDestroy(c->comm_fence);
     hipEventDestroy(c->comm_done);
@@ -1233,13 +1235,11 @@ int sarx_power_stats_dev(sarx_ctx* c, const void* buf, size_t n, double* max_abs
     NEED_CTX(c);
     if (!buf || !n) return fail(c, SARX_ERR_INVALID, "empty buffer");
     const int blocks = 1024;
-    double* d_part = nullptr;
-    HIPCHK(c, hipMalloc(&d_part, 2 * blocks * sizeof(double)));
+    double* d_part = c->power_part_all + (size_t)c->cur_lane * 2048;
     hipError_t e = launch_power_stats((const float2*)buf, n, d_part, blocks, c->stream);
     std::vector<double> part(2 * blocks);
     if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_part);
     HIPCHK(c, e);
     double sum = 0.0, mx = 0.0;
     for (int b = 0; b < blocks; ++b) { sum += part[2 * b]; if (part[2 * b + 1] > mx) mx = part[2 * b + 1]; }

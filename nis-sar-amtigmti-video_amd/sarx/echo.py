@@ -26,24 +26,27 @@ def synth_device(ctx, model, tgt_pos, tgt_vel, t_pulse, tx_pos, aux, amp_or_rcs,
     Returns the DeviceBuffer holding raw [n_pulses x n_samples] complex64 (``out`` if given; ``accumulate`` adds to it)."""
     lib = ctx.lib
     n_pulses, n_tgt, n_samp = tx_pos.shape[0], tgt_pos.shape[0], t_fast_abs.size
-    d_tp = ctx.to_device(np.ascontiguousarray(tgt_pos, dtype=np.float64))
-    d_tv = ctx.to_device(np.ascontiguousarray(tgt_vel, dtype=np.float64)) if tgt_vel is not None else None
-    d_t = ctx.to_device(np.ascontiguousarray(t_pulse, dtype=np.float64)) if t_pulse is not None else None
-    d_tx = ctx.to_device(np.ascontiguousarray(tx_pos, dtype=np.float64))
-    d_aux = ctx.to_device(np.ascontiguousarray(aux, dtype=np.float64)) if aux is not None else None
-    d_tf = ctx.to_device(np.ascontiguousarray(t_fast_abs, dtype=np.float64))
+    # the small tables live in per-context scratch buffers: a frame loop (sar_batch_sim.py:303-331) calls this once per frame, and
+    # ten hipMalloc / hipFree pairs per frame cost more than the tables' upload
+    up = lambda tag, a, dt: ctx.scratch_upload("echo." + tag, np.ascontiguousarray(a, dtype=dt))
+    d_tp = up("tp", tgt_pos, np.float64)
+    d_tv = up("tv", tgt_vel, np.float64) if tgt_vel is not None else None
+    d_t = up("t", t_pulse, np.float64) if t_pulse is not None else None
+    d_tx = up("tx", tx_pos, np.float64)
+    d_aux = up("aux", aux, np.float64) if aux is not None else None
+    d_tf = up("tf", t_fast_abs, np.float64)
     if model == 2:
-        d_rcs = ctx.to_device(np.ascontiguousarray(amp_or_rcs, dtype=np.float64))
+        d_rcs = up("rcs", amp_or_rcs, np.float64)
         d_amp = None
     else:
         d_rcs = None
-        d_amp = ctx.to_device(np.ascontiguousarray(amp_or_rcs, dtype=np.float32))
+        d_amp = up("amp", amp_or_rcs, np.float32)
     d_raw = out if out is not None else ctx.alloc(n_pulses * n_samp * 8)
     if d_raw.nbytes < n_pulses * n_samp * 8:
         raise ValueError("out buffer too small")
     step = max(1, min(_PULSE_CHUNK, n_pulses, (512 << 20) // max(20 * n_tgt, 1)))
-    d_tab = ctx.alloc(step * n_tgt * 16)
-    d_apt = ctx.alloc(step * n_tgt * 4) if model == 2 else None
+    d_tab = ctx.scratch("echo.tab", step * n_tgt * 16)
+    d_apt = ctx.scratch("echo.apt", step * n_tgt * 4) if model == 2 else None
     ptr = lambda b, off=0: (b.ptr + off) if b is not None else None
     for i0 in range(0, n_pulses, step):
         n = min(step, n_pulses - i0)
@@ -57,9 +60,6 @@ def synth_device(ctx, model, tgt_pos, tgt_vel, t_pulse, tx_pos, aux, amp_or_rcs,
             check(lib.sarx_echo_synth_dev(ctx.h, d_tab.ptr, d_amp.ptr, d_tf.ptr, n, n_tgt, n_samp, float(kr), float(t_p), dst,
                                           1 if accumulate else 0), ctx.h)
     ctx.sync()
-    for b in (d_tp, d_tv, d_t, d_tx, d_aux, d_tf, d_rcs, d_amp, d_tab, d_apt):
-        if b is not None:
-            b.release()
     return d_raw
 
 

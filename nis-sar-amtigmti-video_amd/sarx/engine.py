@@ -141,6 +141,8 @@ class Context:
         self.device_id = int(device_id)
         self._live = {}
         self._plans = weakref.WeakSet()
+        self._scratch = {}             # (tag, lane) -> DeviceBuffer
+        self._lane = 0
         self._pinned_free = {}         # nbytes -> [ptr, ...]
         self._pinned_seen = {}         # nbytes -> requests so far
         self._pinned_total = 0         # bytes handed out + bytes kept free
@@ -161,6 +163,22 @@ class Context:
                 self._pinned_free.clear()
             self.lib.sarx_destroy(self.h)
             self.h = None
+
+    # -- small device scratch kept across calls --
+    def scratch(self, tag, nbytes):
+        """A device buffer of at least nbytes that lives as long as the context, one per (tag, current lane): tables a frame loop
+        uploads every frame (target positions, platform track, ...) reuse it instead of a hipMalloc / hipFree pair per call."""
+        key = (tag, self._lane)
+        b = self._scratch.get(key)
+        if b is None or b.ptr is None or b.nbytes < nbytes:
+            if b is not None:
+                b.release()
+            b = self._scratch[key] = DeviceBuffer(self, max(int(nbytes), 256))
+        return b
+
+    def scratch_upload(self, tag, arr):
+        arr = np.ascontiguousarray(arr)
+        return self.scratch(tag, arr.nbytes).upload(arr)
 
     # -- pooled page-locked result arrays --
     def pinned_empty(self, shape, dtype):
@@ -217,6 +235,7 @@ class Context:
         """Every later enqueue of this context goes to compute stream `lane` (0..3): consecutive independent frames on
         alternating lanes - each with its own plan and buffers - overlap on the GPU (sarx_select_lane)."""
         check(self.lib.sarx_select_lane(self.h, int(lane)), self.h)
+        self._lane = int(lane)
 
     def set_range_cus(self, cus):
         """Persistent range launches size their grid for `cus` compute units (0 = all): with frames in flight the rest of the

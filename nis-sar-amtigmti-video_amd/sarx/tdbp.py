@@ -129,6 +129,7 @@ class TdbpPlan:
         self.h = C.c_void_p()
         check(ctx.lib.sarx_tdbp_plan_create(ctx.h, *self.shape, C.byref(prm), C.byref(self.h)), ctx.h)
         ctx._plans.add(self)          # closed with the context, before sarx_destroy
+        self._d_img = None            # the device image of the device-in path, kept across frames (a frame loop allocated and freed it per frame)
 
     def focus(self, raw, pos_plat, vel_plat, t_start, vel_focus, t_pulses, scene_size, want_rc=False):
         n_p, n_s, nx, ny = self.shape
@@ -141,12 +142,11 @@ class TdbpPlan:
         img = np.empty((ny, nx), dtype=np.complex128)
         lib, ctx = self.ctx.lib, self.ctx
         if isinstance(raw, DeviceBuffer):
-            d_img = ctx.alloc(img.nbytes)
+            if self._d_img is None:
+                self._d_img = ctx.alloc(img.nbytes)
             check(lib.sarx_tdbp_focus_dev(self.h, raw.ptr, pos.ctypes.data, vel.ctypes.data, tp.ctypes.data, float(t_start),
-                                          vf.ctypes.data, float(scene_size), d_img.ptr), ctx.h)
-            img = d_img.download(np.complex128, (ny, nx))
-            d_img.release()
-            return img
+                                          vf.ctypes.data, float(scene_size), self._d_img.ptr), ctx.h)
+            return self._d_img.download(np.complex128, (ny, nx))
         x = np.ascontiguousarray(raw, dtype=np.complex64)
         if x.shape != (n_p, n_s):
             raise ValueError(f"raw must be [{n_p} x {n_s}]")
@@ -165,6 +165,9 @@ class TdbpPlan:
     def close(self):
         if self.h and self.ctx.h is not None:
             self.ctx.lib.sarx_tdbp_plan_destroy(self.h)
+            if self._d_img is not None:
+                self._d_img.release()
+        self._d_img = None
         self.h = None
 
     def __del__(self):
