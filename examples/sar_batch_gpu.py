@@ -68,29 +68,56 @@ def main():
             state = {"d_raw": None, "n_sp": 0, "local_max": 0.0}
             t0 = time.time()
 
-            def process_frame(f):
+            def enqueue_frame(f, d_raw, d_image=None):
+                """One frame of :303-331 on the current lane: echo (:308-311), noise relative to max |raw|^2 taken on the device
+                (:313-314; sarx.add_noise_rel_dev = power_stats + add_noise_dev without the host round trip, same samples), TDBP
+                (:318-321).  With d_image the call only enqueues; without it the image comes back to the host."""
                 i0 = f * STEP_PULSES
                 t_cpi, p_cpi, v_cpi = t_vec_all[i0:i0 + CPI_PULSES], pos_sat_all[i0:i0 + CPI_PULSES], vel_sat_all[i0:i0 + CPI_PULSES]
                 d_raw, t_st, n_sp, v_tgt = sarx.run_physics_spotlight(base_target, t_cpi, p_cpi, v_cpi, heading_deg=h,
                                                                       speed=v["speed"], l_ant=L_ANT, consts=k, device=True,
-                                                                      out=state["d_raw"], ctx=ctx)   # one pulse buffer for all frames
-                state["d_raw"], state["n_sp"] = d_raw, n_sp
-                n = len(t_cpi) * n_sp
-                sig_p, _ = sarx.power_stats(d_raw, n)                                          # :313 max |raw|^2
-                sarx.add_noise_dev(d_raw, n, sig_p, snr_db_raw + k["SNR_BOOST_DB"], k["SCR_DB"], k["K_NU"],
-                                   seed=a.seed * 100003 + f)                                   # :314
+                                                                      out=d_raw, ctx=ctx, sync=d_image is None)
+                state["n_sp"] = n_sp
+                sarx.add_noise_rel_dev(d_raw, len(t_cpi) * n_sp, snr_db_raw + k["SNR_BOOST_DB"], k["SCR_DB"], k["K_NU"],
+                                       seed=a.seed * 100003 + f, ref="max")
                 vf = v_tgt if focus_tgt else np.zeros(3)
                 img = sarx.tdbp_gpu(d_raw, p_cpi, v_cpi, t_st, n_sp, vel_focus=vf, t_pulses=t_cpi,
-                                    scene_size=v["swath"], nx=a.nx, ny=a.nx, consts=k, ctx=ctx)   # :318-321
-                img = img.astype(np.complex64)
-                state["local_max"] = max(state["local_max"], float(np.abs(img).max()))         # this rank's share of g_max (:337)
-                return img.view(np.float32)                                                    # stack slot [ny x 2 nx]
+                                    scene_size=v["swath"], nx=a.nx, ny=a.nx, consts=k, ctx=ctx, d_image=d_image)
+                return d_raw, img
 
-            comm = TorchStackComm() if world > 1 else LocalStackComm()
-            stack = np.ascontiguousarray(run_batch_host(frame_ids, world, rank, process_frame, comm,
-                                                              slot_shape=(a.nx, 2 * a.nx))).view(np.complex64)
-            if state["d_raw"] is not None:
-                state["d_raw"].release()
+            if world == 1:
+                # one GPU: two frames in flight on two lanes of the context, each lane with its own pulse buffer (and, inside
+                # tdbp_gpu, its own plan); no host synchronisation inside the loop - the frames land in one device stack that is
+                # downloaded once at the end
+                class _At:
+                    def __init__(self, ptr):
+                        self.ptr = ptr
+                slot = a.nx * a.nx * 16
+                d_stack = ctx.alloc(max(len(frame_ids), 1) * slot)
+                d_raws = [None, None]
+                for i, f in enumerate(frame_ids):
+                    ctx.select_lane(i & 1)
+                    d_raws[i & 1], _ = enqueue_frame(f, d_raws[i & 1], _At(d_stack.ptr + i * slot))
+                ctx.select_lane(0)
+                ctx.lanes_join()
+                stack = d_stack.download(np.complex128, (len(frame_ids), a.nx, a.nx)).astype(np.complex64)
+                state["local_max"] = float(np.abs(stack).max()) if stack.size else 0.0
+                for b in (d_stack, *d_raws):
+                    if b is not None:
+                        b.release()
+                comm = LocalStackComm()
+            else:
+                def process_frame(f):
+                    state["d_raw"], img = enqueue_frame(f, state["d_raw"])                         # one pulse buffer for all frames
+                    img = img.astype(np.complex64)
+                    state["local_max"] = max(state["local_max"], float(np.abs(img).max()))         # this rank's share of g_max (:337)
+                    return img.view(np.float32)                                                    # stack slot [ny x 2 nx]
+
+                comm = TorchStackComm()
+                stack = np.ascontiguousarray(run_batch_host(frame_ids, world, rank, process_frame, comm,
+                                                            slot_shape=(a.nx, 2 * a.nx))).view(np.complex64)
+                if state["d_raw"] is not None:
+                    state["d_raw"].release()
             ctx.sync()
             # g_max = max over ALL frames of max|frame| (:337-338): each rank has reduced the frames it focused, one float is
             # all-reduced with max (every rank takes part) - nobody scans the gathered stack for it

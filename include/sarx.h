@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 204   /* 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join); 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
+#define SARX_VERSION 204   /* 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -267,6 +267,13 @@ int sarx_fill_noise_c64(sarx_ctx* ctx, void* d_buf, size_t n, uint64_t seed);
  * Counter-based (seed, index); clutter_power = 0 skips the clutter. */
 int sarx_add_ocean_noise_dev(sarx_ctx* ctx, void* d_buf, size_t n, double noise_std, double clutter_power, double k_nu,
                              uint64_t seed);
+/* The same with the levels taken on the device, relative to the buffer's own power, so that a frame loop needs no host round trip
+ * between the echo and its noise: reference power = max |x|^2 (ref_is_max, sar_batch_sim.py:313-314) or mean |x|^2
+ * (sar_satellite_sim.py:333), sigma = sqrt(ref / snr_lin / 2), clutter power = ref / scr_lin (scr_lin = 0: thermal noise only), with
+ * snr_lin = 10^(snr_db / 10), scr_lin = 10^(scr_db / 10).  Same partial sums in the same order and the same arithmetic as
+ * sarx_power_stats_dev + sarx_add_ocean_noise_dev with the levels computed on the host: bit-identical samples.  Asynchronous. */
+int sarx_add_ocean_noise_rel_dev(sarx_ctx* ctx, void* d_buf, size_t n, int ref_is_max, double snr_lin, double scr_lin, double k_nu,
+                                 uint64_t seed);
 /* max and mean of |x|^2 over a complex64 device buffer (blocking): the reference powers of
  * sar_batch_sim.py:316 (max) and sar_satellite_sim.py:333 (mean).  Either output may be NULL. */
 int sarx_power_stats_dev(sarx_ctx* ctx, const void* d_buf, size_t n, double* max_abs2, double* mean_abs2);

@@ -195,7 +195,10 @@ hipError_t launch_multilook(const float2* in, float* out, int rows, int cols, in
 hipError_t launch_look_finish(const float* part, float* out, int out_rows, int cols, int looks, hipStream_t st);
 hipError_t launch_fill_noise(float2* buf, size_t n, uint64_t seed, hipStream_t st);
 
-hipError_t launch_ocean_noise(float2* buf, size_t n, float sigma, float clutter_power, float nu, uint64_t seed, hipStream_t st);
+hipError_t launch_ocean_noise(float2* buf, size_t n, float sigma, float clutter_power, float nu, uint64_t seed, hipStream_t st,
+                              const float* levels = nullptr);
+hipError_t launch_noise_levels(const double* part, int blocks, size_t n, int ref_is_max, double snr_lin, double scr_lin, float* levels,
+                               hipStream_t st);
 hipError_t launch_power_stats(const float2* buf, size_t n, double* part, int blocks, hipStream_t st);
 
 // echo.hip

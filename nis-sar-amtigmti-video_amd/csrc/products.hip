@@ -432,8 +432,11 @@ __device__ float gamma_unit_mean(Rng& g, float nu) {
     if (nu < 1.0f) out *= __powf(g.uniform(), 1.0f / nu);
     return out / nu;                                                   // scale 1/nu: unit mean
 }
+// levels: optional {sigma, clutter_power} on the device (noise_levels_kernel), so that the noise can follow the power reduction
+// without a host round trip; the host-parameter form passes nullptr
 __global__ __launch_bounds__(256) void ocean_noise_kernel(cf* buf, size_t n, float sigma, float clutter_power, float nu,
-                                                          uint64_t seed) {
+                                                          uint64_t seed, const float* __restrict__ levels) {
+    if (levels) { sigma = levels[0]; clutter_power = levels[1]; }
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         Rng g{mix64(seed * 0xD1342543DE82EF95ull + i), 0};
@@ -453,11 +456,12 @@ __global__ __launch_bounds__(256) void ocean_noise_kernel(cf* buf, size_t n, flo
         buf[i] = x;
     }
 }
-hipError_t launch_ocean_noise(cf* buf, size_t n, float sigma, float clutter_power, float nu, uint64_t seed, hipStream_t st) {
+hipError_t launch_ocean_noise(cf* buf, size_t n, float sigma, float clutter_power, float nu, uint64_t seed, hipStream_t st,
+                              const float* levels) {
     size_t b = (n + 255) / 256;
     if (b > 16384) b = 16384;
     if (b < 1) b = 1;
-    hipLaunchKernelGGL(ocean_noise_kernel, dim3((unsigned)b), dim3(256), 0, st, buf, n, sigma, clutter_power, nu, seed);
+    hipLaunchKernelGGL(ocean_noise_kernel, dim3((unsigned)b), dim3(256), 0, st, buf, n, sigma, clutter_power, nu, seed, levels);
     return hipGetLastError();
 }
 
@@ -489,6 +493,23 @@ __global__ __launch_bounds__(256) void power_stats_kernel(const cf* buf, size_t 
 }
 hipError_t launch_power_stats(const cf* buf, size_t n, double* part, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(power_stats_kernel, dim3(blocks), dim3(256), 0, st, buf, n, part);
+    return hipGetLastError();
+}
+// The host's finish of the partials and its noise levels, on the device and in the same order and arithmetic: reference power =
+// max |x|^2 (sar_batch_sim.py:313) or mean |x|^2 (sar_satellite_sim.py:333); sigma = sqrt(ref / snr_lin / 2), clutter = ref / scr_lin
+// (scr_lin = 0: thermal noise only) - sar_batch_sim.py:67-78, sar_satellite_sim.py:334-343.
+__global__ void noise_levels_kernel(const double* __restrict__ part, int blocks, double n, int ref_is_max, double snr_lin, double scr_lin,
+                                    float* __restrict__ levels) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sum = 0.0, mx = 0.0;
+    for (int b = 0; b < blocks; ++b) { sum += part[2 * b]; if (part[2 * b + 1] > mx) mx = part[2 * b + 1]; }
+    const double ref = ref_is_max ? mx : sum / n;
+    levels[0] = (float)sqrt(ref / snr_lin / 2.0);
+    levels[1] = scr_lin > 0.0 ? (float)(ref / scr_lin) : 0.f;
+}
+hipError_t launch_noise_levels(const double* part, int blocks, size_t n, int ref_is_max, double snr_lin, double scr_lin, float* levels,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(noise_levels_kernel, dim3(1), dim3(64), 0, st, part, blocks, (double)n, ref_is_max, snr_lin, scr_lin, levels);
     return hipGetLastError();
 }
 

@@ -106,6 +106,7 @@ struct sarx_ctx {
     float* ati_part_max_all = nullptr;     // reduction scratch, one set per lane (two frames in flight must not share it)
     double2* ati_part_sum_all = nullptr;
     double* ati_out3_all = nullptr;
+    static constexpr int POWER_STRIDE = 2048 + 8;   // per lane: 1024 {sum, max} partials, then the two fp32 noise levels
     double* power_part_all = nullptr;       // sarx_power_stats_dev partials, one set per lane (it used to hipMalloc / hipFree per call)
     float* ati_part_max_() const { return ati_part_max_all + (size_t)cur_lane * 4096; }
     double2* ati_part_sum_() const { return ati_part_sum_all + (size_t)cur_lane * 4096; }
@@ -313,7 +314,7 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
     HIPCHK(nullptr, hipMalloc(&c->ati_part_max_all, sarx_ctx::LANES * 4096 * sizeof(float)));
     HIPCHK(nullptr, hipMalloc(&c->ati_part_sum_all, sarx_ctx::LANES * 4096 * sizeof(double2)));
     HIPCHK(nullptr, hipMalloc(&c->ati_out3_all, sarx_ctx::LANES * 4 * sizeof(double)));
-    HIPCHK(nullptr, hipMalloc(&c->power_part_all, sarx_ctx::LANES * 2048 * sizeof(double)));
+    HIPCHK(nullptr, hipMalloc(&c->power_part_all, sarx_ctx::LANES * sarx_ctx::POWER_STRIDE * sizeof(double)));
     *out_ctx = c;
     return SARX_OK;
 }
@@ -1231,11 +1232,24 @@ int sarx_add_ocean_noise_dev(sarx_ctx* c, void* buf, size_t n, double noise_std,
     if (n) HIPCHK(c, launch_ocean_noise((float2*)buf, n, (float)noise_std, (float)clutter_power, (float)k_nu, seed, c->stream));
     return SARX_OK;
 }
+int sarx_add_ocean_noise_rel_dev(sarx_ctx* c, void* buf, size_t n, int ref_is_max, double snr_lin, double scr_lin, double k_nu,
+                                 uint64_t seed) {
+    NEED_CTX(c);
+    if (!buf || !n) return fail(c, SARX_ERR_INVALID, "empty buffer");
+    if (!(snr_lin > 0) || !(scr_lin >= 0) || (scr_lin > 0 && !(k_nu > 0)))
+        return fail(c, SARX_ERR_INVALID, "snr_lin must be > 0, scr_lin >= 0 (0 = thermal noise only) and k_nu > 0");
+    double* d_part = c->power_part_all + (size_t)c->cur_lane * sarx_ctx::POWER_STRIDE;
+    float* d_levels = reinterpret_cast<float*>(d_part + 2048);
+    HIPCHK(c, launch_power_stats((const float2*)buf, n, d_part, 1024, c->stream));
+    HIPCHK(c, launch_noise_levels(d_part, 1024, n, ref_is_max != 0, snr_lin, scr_lin, d_levels, c->stream));
+    HIPCHK(c, launch_ocean_noise((float2*)buf, n, 0.f, 0.f, (float)k_nu, seed, c->stream, d_levels));
+    return SARX_OK;
+}
 int sarx_power_stats_dev(sarx_ctx* c, const void* buf, size_t n, double* max_abs2, double* mean_abs2) {
     NEED_CTX(c);
     if (!buf || !n) return fail(c, SARX_ERR_INVALID, "empty buffer");
     const int blocks = 1024;
-    double* d_part = c->power_part_all + (size_t)c->cur_lane * 2048;
+    double* d_part = c->power_part_all + (size_t)c->cur_lane * sarx_ctx::POWER_STRIDE;
     hipError_t e = launch_power_stats((const float2*)buf, n, d_part, blocks, c->stream);
     std::vector<double> part(2 * blocks);
     if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);

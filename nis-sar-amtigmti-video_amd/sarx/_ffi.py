@@ -102,6 +102,7 @@ SIGNATURES = {
     "sarx_multilook_dev": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "sarx_fill_noise_c64": (_i, [_vp, _vp, _sz, _u64]),
     "sarx_add_ocean_noise_dev": (_i, [_vp, _vp, _sz, _d, _d, _d, _u64]),
+    "sarx_add_ocean_noise_rel_dev": (_i, [_vp, _vp, _sz, _i, _d, _d, _d, _u64]),
     "sarx_power_stats_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "sarx_echo_synth_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _vp, _i]),
     "sarx_echo_geometry_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _vp, _vp]),

@@ -20,10 +20,11 @@ _PULSE_CHUNK = 4096          # bounds the [pulses x targets] fp64 table held on 
 
 
 def synth_device(ctx, model, tgt_pos, tgt_vel, t_pulse, tx_pos, aux, amp_or_rcs, t_fast_abs, kr, t_p, c_light, fc,
-                 l_ant=0.0, wavelength=0.0, out=None, accumulate=False):
+                 l_ant=0.0, wavelength=0.0, out=None, accumulate=False, sync=True):
     """Geometry kernel + sample kernel, pulse chunk by pulse chunk, entirely on the device.
     model 0/1: amp_or_rcs = sqrt(rcs) per target; model 2 (spotlight): rcs per target (the gain is per pulse).
-    Returns the DeviceBuffer holding raw [n_pulses x n_samples] complex64 (``out`` if given; ``accumulate`` adds to it)."""
+    Returns the DeviceBuffer holding raw [n_pulses x n_samples] complex64 (``out`` if given; ``accumulate`` adds to it).
+    ``sync=False`` only enqueues (a frame loop with frames in flight); the tables live in per-lane scratch either way."""
     lib = ctx.lib
     n_pulses, n_tgt, n_samp = tx_pos.shape[0], tgt_pos.shape[0], t_fast_abs.size
     # the small tables live in per-context scratch buffers: a frame loop (sar_batch_sim.py:303-331) calls this once per frame, and
@@ -59,7 +60,8 @@ def synth_device(ctx, model, tgt_pos, tgt_vel, t_pulse, tx_pos, aux, amp_or_rcs,
         else:
             check(lib.sarx_echo_synth_dev(ctx.h, d_tab.ptr, d_amp.ptr, d_tf.ptr, n, n_tgt, n_samp, float(kr), float(t_p), dst,
                                           1 if accumulate else 0), ctx.h)
-    ctx.sync()
+    if sync:
+        ctx.sync()
     return d_raw
 
 

@@ -45,6 +45,20 @@ def add_noise_dev(d_buf, n, ref_power, snr_db, scr_db=SCR_DB, k_nu=K_NU, seed=0,
                                            int(seed) & 0xFFFFFFFFFFFFFFFF), ctx.h)
 
 
+def add_noise_rel_dev(d_buf, n, snr_db, scr_db=SCR_DB, k_nu=K_NU, seed=0, ref="max", ctx=None):
+    """power_stats + add_noise_dev in one call that never visits the host: the levels are taken on the device relative to the
+    buffer's own max |x|^2 (ref="max": sar_batch_sim.py:313-314) or mean |x|^2 (ref="mean": sar_satellite_sim.py:333), by the same
+    partial sums and arithmetic as the two-call form - the samples are bit-identical - and the call only enqueues, so a frame loop
+    can keep frames in flight (sarx_add_ocean_noise_rel_dev).  ``scr_db=None`` adds thermal noise only."""
+    if ref not in ("max", "mean"):
+        raise ValueError("ref must be 'max' or 'mean'")
+    ctx = ctx or d_buf.ctx
+    snr_lin = 10 ** (snr_db / 10)
+    scr_lin = 0.0 if scr_db is None else 10 ** (scr_db / 10)
+    check(ctx.lib.sarx_add_ocean_noise_rel_dev(ctx.h, d_buf.ptr, int(n), 1 if ref == "max" else 0, float(snr_lin), float(scr_lin),
+                                               float(k_nu), int(seed) & 0xFFFFFFFFFFFFFFFF), ctx.h)
+
+
 def add_ocean_noise(raw_data, snr_db, scr_db=SCR_DB, k_nu=K_NU, *, seed=0, ctx=None):
     """Drop-in for sar_satellite_sim.py:331-344 (noise relative to the MEAN signal power).  A NumPy array is
     returned as a new complex64 array; a DeviceBuffer is modified in place (pass its sample count as

@@ -90,11 +90,12 @@ def spotlight_window(consts=None):
 
 
 def run_physics_spotlight(base_targets, t_vec, pos_sat, vel_sat, heading_deg, speed, l_ant, *, consts=None, ctx=None,
-                          device=False, out=None):
+                          device=False, out=None, sync=True):
     """Spotlight echo of a rigid target moving at ``speed`` along ``heading_deg``; drop-in for
     sar_batch_sim.py:85-169.  returns (raw [len(t_vec) x num_samples] complex64, t_start, num_samples, v_tgt).
     ``device=True`` leaves raw on the GPU (a DeviceBuffer) for ``tdbp_gpu``; ``out`` (implies device) is a
-    DeviceBuffer of at least len(t_vec) * num_samples * 8 bytes to fill instead of allocating one per call."""
+    DeviceBuffer of at least len(t_vec) * num_samples * 8 bytes to fill instead of allocating one per call; ``sync=False``
+    (device output only) returns as soon as the kernels are enqueued on the current lane."""
     k = consts or batch_constants()
     Cc, FC, T_P, K_RATE, Lambda = k["C"], k["FC"], k["T_P"], k["K_RATE"], k["Lambda"]
     ctx = ctx or default_context()
@@ -111,7 +112,7 @@ def run_physics_spotlight(base_targets, t_vec, pos_sat, vel_sat, heading_deg, sp
     # per pulse and target: moved target (:127), bistatic delay with the receiver displaced by v_sat * 2 d_tx / C
     # (:128-133), antenna pattern (:134-144), amplitude rcs * gain (:150): geometry kernel, then the sample kernel
     d_raw = synth_device(ctx, 2, p0, v_tgt, t_vec, pos_sat, vel_sat, rcs, t_fast_abs, K_RATE, T_P, Cc, FC, l_ant=l_ant,
-                         wavelength=Lambda, out=out)
+                         wavelength=Lambda, out=out, sync=sync or not (device or out is not None))
     if device or out is not None:
         return d_raw, t_start, num_samples, v_tgt
     raw = d_raw.download(np.complex64, (t_vec.size, num_samples))
@@ -131,7 +132,7 @@ class TdbpPlan:
         ctx._plans.add(self)          # closed with the context, before sarx_destroy
         self._d_img = None            # the device image of the device-in path, kept across frames (a frame loop allocated and freed it per frame)
 
-    def focus(self, raw, pos_plat, vel_plat, t_start, vel_focus, t_pulses, scene_size, want_rc=False):
+    def focus(self, raw, pos_plat, vel_plat, t_start, vel_focus, t_pulses, scene_size, want_rc=False, d_image=None):
         n_p, n_s, nx, ny = self.shape
         pos = np.ascontiguousarray(pos_plat, dtype=np.float64)
         vel = np.ascontiguousarray(vel_plat, dtype=np.float64)
@@ -141,6 +142,12 @@ class TdbpPlan:
             raise ValueError("pos_plat/vel_plat must be [n_pulses x 3], t_pulses [n_pulses], vel_focus [3]")
         img = np.empty((ny, nx), dtype=np.complex128)
         lib, ctx = self.ctx.lib, self.ctx
+        if isinstance(raw, DeviceBuffer) and d_image is not None:      # device in, device out: only enqueues, returns nothing
+            check(lib.sarx_tdbp_focus_dev(self.h, raw.ptr, pos.ctypes.data, vel.ctypes.data, tp.ctypes.data, float(t_start),
+                                          vf.ctypes.data, float(scene_size), d_image.ptr), ctx.h)
+            return None
+        if d_image is not None:
+            raise ValueError("d_image needs a device input")
         if isinstance(raw, DeviceBuffer):
             if self._d_img is None:
                 self._d_img = ctx.alloc(img.nbytes)
@@ -181,18 +188,20 @@ _plans = {}
 
 
 def tdbp_gpu(raw_t, pos_plat, vel_plat, t_start, num_samples, vel_focus, t_pulses, scene_size, nx=512, ny=512, *,
-             consts=None, ctx=None):
+             consts=None, ctx=None, d_image=None):
     """Back-projection image of one CPI; drop-in for sar_batch_sim.py:171-238.
     raw_t: [n_pulses x num_samples] complex (NumPy array, or the DeviceBuffer of run_physics_spotlight(device=True)).
-    returns complex128 [ny x nx]."""
+    returns complex128 [ny x nx].  ``d_image`` (device input only): a device buffer / address holder for the complex128 [ny x nx]
+    image - the call then only enqueues on the current lane and returns None (a frame loop with frames in flight; every lane gets
+    its own plan, i.e. its own scratch)."""
     k = consts or batch_constants()
     ctx = ctx or default_context()
     n_p = len(t_pulses)
-    key = (id(ctx), n_p, int(num_samples), int(nx), int(ny), k["C"], k["FC"], k["FS"], k["T_P"], k["K_RATE"])
+    key = (id(ctx), getattr(ctx, "_lane", 0), n_p, int(num_samples), int(nx), int(ny), k["C"], k["FC"], k["FS"], k["T_P"], k["K_RATE"])
     plan = _plans.get(key)
     if plan is None or plan.h is None:         # closed together with its Context: never reuse a dead handle
         _plans.pop(key, None)
-        if len(_plans) >= 4:
+        if len(_plans) >= 8:
             _plans.pop(next(iter(_plans))).close()
         plan = _plans[key] = TdbpPlan(ctx, n_p, num_samples, nx, ny, k)
-    return plan.focus(raw_t, pos_plat, vel_plat, t_start, vel_focus, t_pulses, scene_size)
+    return plan.focus(raw_t, pos_plat, vel_plat, t_start, vel_focus, t_pulses, scene_size, d_image=d_image)

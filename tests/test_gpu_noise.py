@@ -62,3 +62,26 @@ def test_add_ocean_noise_and_power_stats():
     assert abs(added / want - 1) < 0.05
     snr, gain = sarx.calculate_snr_db(509e3, 50000.0, 0.031, 500e6, 1.2)
     assert np.isfinite(snr) and abs(gain - 10 * np.log10(4 * np.pi * 3.5 * 0.5 * 0.6 / 0.031 ** 2)) < 1e-9
+
+
+@pytest.mark.parametrize("ref,scr_db", [("max", 12.0), ("mean", 12.0), ("max", None)])
+def test_relative_noise_on_the_device_equals_the_two_call_form(ref, scr_db):
+    """sarx.add_noise_rel_dev (levels taken on the device from the buffer's own max / mean power, no host round trip) adds exactly the
+    samples of power_stats + add_noise_dev with the levels computed on the host (sar_batch_sim.py:313-314, sar_satellite_sim.py:333-343):
+    same partial sums in the same order, same arithmetic."""
+    import sarx
+    ctx = sarx.default_context()
+    rng = np.random.default_rng(5)
+    n = 1_000_003
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * rng.uniform(0.1, 3.0, n)).astype(np.complex64)
+    d_a, d_b = ctx.to_device(x), ctx.to_device(x)
+    mx, mean = sarx.power_stats(d_a, n)
+    assert abs(mx - float((np.abs(x.astype(np.complex128)) ** 2).max())) < 1e-5 * mx
+    sarx.add_noise_dev(d_a, n, mx if ref == "max" else mean, 9.0, scr_db, 1.5, seed=77)
+    sarx.add_noise_rel_dev(d_b, n, 9.0, scr_db, 1.5, seed=77, ref=ref)
+    a, b = d_a.download(np.complex64, (n,)), d_b.download(np.complex64, (n,))
+    np.testing.assert_array_equal(a, b)
+    assert np.abs(a - x).max() > 0
+    with pytest.raises(ValueError):
+        sarx.add_noise_rel_dev(d_b, n, 9.0, scr_db, 1.5, ref="median")
+    d_a.release(); d_b.release()
