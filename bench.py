@@ -308,6 +308,7 @@ def main():
     for i in range(L):
         ctx.fill_noise(d_ins[i], n * n, 1000 + rank + 7919 * i)
     plan, d_in, d_img = plans[0], d_ins[0], d_imgs[0]
+    lane_ids = ctx.concurrent_lanes(L)                   # lanes that really run side by side (HIP may put two streams on one hardware queue)
 
     # ---- collective: RCCL over xGMI; gloo through host memory only if RCCL cannot come up on every rank -------------
     use_rccl, host_comm, collective, rccl = False, None, None, None
@@ -330,7 +331,7 @@ def main():
 
     def step(s, mark, lanes=L):
         lane = s % lanes
-        ctx.select_lane(lane)
+        ctx.select_lane(lane_ids[lane])
         ctx.set_range_cus(range_cus if lanes > 1 else 0)      # frames in flight: the persistent range launch leaves CUs to the other lane
         plan, d_in, d_img = plans[lane], d_ins[lane], d_imgs[lane]
         if mark and 2 * s + 1 < 256:
@@ -491,6 +492,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "c64 (phase arguments f64)", "data": "synthetic",
             "config": {"workload": f"{n}x{n} complex64 single-channel CSA focus, echo resident in HBM",
                        "frames_per_step_per_gpu": 1, "frames_in_flight_per_gpu": L, "range_launch_cus": range_cus if L > 1 else "all",
+                       "lanes": lane_ids, "lane_probe_ratio": {str(k2): round(v2, 2) for k2, v2 in ctx._lane_ratios.items()},
                        "range_passes": "fused 2+3" if not a.unfused else "separate",
                        "image_layout": "[n_az x n_rg]; img.T returned as a view like the reference",
                        "parallelism": f"frames sharded 1/GPU x{world}" +

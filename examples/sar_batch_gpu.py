@@ -95,8 +95,9 @@ def main():
                 slot = a.nx * a.nx * 16
                 d_stack = ctx.alloc(max(len(frame_ids), 1) * slot)
                 d_raws = [None, None]
+                lane_ids = ctx.concurrent_lanes(2)              # two lanes that really run side by side
                 for i, f in enumerate(frame_ids):
-                    ctx.select_lane(i & 1)
+                    ctx.select_lane(lane_ids[i & 1])
                     d_raws[i & 1], _ = enqueue_frame(f, d_raws[i & 1], _At(d_stack.ptr + i * slot))
                 ctx.select_lane(0)
                 ctx.lanes_join()

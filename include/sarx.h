@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 204   /* 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
+#define SARX_VERSION 204   /* 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -124,6 +124,11 @@ int sarx_lanes_join(sarx_ctx* ctx);
  * compute units instead of all of them (0 = all, the default; 192 of 256 measured best with two lanes: 3.93-3.96 ms per 16384^2
  * frame on every box met, against 4.1-4.3 ms when both lanes ask for the whole chip).  Results do not depend on it. */
 int sarx_set_range_cus(sarx_ctx* ctx, int cus);
+/* Do lanes a and b run side by side?  HIP maps streams onto a few hardware queues; two lanes that share one take turns and frames in
+ * flight on them gain nothing (4.6 against 4.0 ms per 16384^2 frame, profiles/r04_ai_lane_probe_boxes.log).  Two small launches (64
+ * one-wave workgroups spinning `us` microseconds) are timed on lane a alone and on a and b together: *ratio = together / alone, 1.0 =
+ * side by side, 2.0 = taking turns.  Blocking, a few milliseconds; creates the lanes if needed. */
+int sarx_probe_lanes(sarx_ctx* ctx, int lane_a, int lane_b, int us, double* ratio);
 /* HIP events on the ctx stream: record `slot` (0..255); elapsed ms between two recorded slots */
 int sarx_event_record(sarx_ctx* ctx, int slot);
 int sarx_event_elapsed_ms(sarx_ctx* ctx, int slot_start, int slot_stop, float* out_ms);

@@ -188,6 +188,7 @@ hipError_t launch_mask_phase(const float* phase, const float* mag, size_t n, flo
 hipError_t launch_mask_phase_frac(const float* phase, const float* mag, size_t n, float frac, const double* out3, float* out,
                                   hipStream_t st);
 hipError_t launch_magnitude(const float2* in, float* out, size_t n, hipStream_t st);
+hipError_t launch_spin(int blocks, unsigned long long cycles, unsigned* sink, hipStream_t st);
 hipError_t launch_max_abs_f32(const float* x, size_t n, float* out, hipStream_t st);   // *out = max(*out, max |x|)
 hipError_t launch_corner_turn(const float2* in, float2* out, int rows, int cols, hipStream_t st);
 hipError_t launch_multilook(const float2* in, float* out, int rows, int cols, int looks, hipStream_t st);

@@ -513,4 +513,16 @@ hipError_t launch_noise_levels(const double* part, int blocks, size_t n, int ref
     return hipGetLastError();
 }
 
+// a launch that occupies `gridDim.x` CUs' worth of one small workgroup each for about `cycles` shader cycles (lane concurrency probe)
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long cycles, unsigned* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+    unsigned x = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < cycles) x += 1;
+    if (x == 0xffffffffu) *sink = x;
+}
+hipError_t launch_spin(int blocks, unsigned long long cycles, unsigned* sink, hipStream_t st) {
+    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(64), 0, st, cycles, sink);
+    return hipGetLastError();
+}
+
 }  // namespace sarx

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -417,6 +418,36 @@ int sarx_select_lane(sarx_ctx* c, int lane) {
     if (!c->lane[lane]) HIPCHK(c, hipStreamCreateWithFlags(&c->lane[lane], hipStreamNonBlocking));
     c->cur_lane = lane;
     c->stream = c->lane[lane];
+    return SARX_OK;
+}
+// How concurrently do two lanes run?  Two small launches (64 one-wave workgroups spinning ~`us` microseconds each) on lanes a and b,
+// timed from the host: *ratio = time of both together / time of one alone - 1.0 when the lanes' hardware queues run side by side,
+// 2.0 when they take turns.
+int sarx_probe_lanes(sarx_ctx* c, int a, int b, int us, double* ratio) {
+    NEED_CTX(c);
+    if (a < 0 || b < 0 || a >= sarx_ctx::LANES || b >= sarx_ctx::LANES || a == b || !ratio || us <= 0)
+        return fail(c, SARX_ERR_INVALID, "bad lane probe arguments");
+    for (int l : {a, b})
+        if (!c->lane[l]) HIPCHK(c, hipStreamCreateWithFlags(&c->lane[l], hipStreamNonBlocking));
+    unsigned* sink = reinterpret_cast<unsigned*>(c->power_part_all);          // never written (the kernel's condition is never true)
+    const unsigned long long cycles = (unsigned long long)us * 100ull;         // s_memrealtime counts at 100 MHz
+    auto wall = [&](bool both, double& ms) -> hipError_t {
+        hipError_t e = sync_all_lanes(c);
+        if (e != hipSuccess) return e;
+        const auto t0 = std::chrono::steady_clock::now();
+        e = launch_spin(64, cycles, sink, c->lane[a]);
+        if (e == hipSuccess && both) e = launch_spin(64, cycles, sink, c->lane[b]);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->lane[a]);
+        if (e == hipSuccess && both) e = hipStreamSynchronize(c->lane[b]);
+        ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return e;
+    };
+    double one = 1e30, two = 1e30, ms = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+        HIPCHK(c, wall(false, ms)); if (ms < one) one = ms;
+        HIPCHK(c, wall(true, ms)); if (ms < two) two = ms;
+    }
+    *ratio = two / one;
     return SARX_OK;
 }
 int sarx_set_range_cus(sarx_ctx* c, int cus) {

@@ -72,6 +72,7 @@ SIGNATURES = {
     "sarx_select_lane": (_i, [_vp, _i]),
     "sarx_lanes_join": (_i, [_vp]),
     "sarx_set_range_cus": (_i, [_vp, _i]),
+    "sarx_probe_lanes": (_i, [_vp, _i, _i, _i, _P(_d)]),
     "sarx_event_record": (_i, [_vp, _i]),
     "sarx_event_elapsed_ms": (_i, [_vp, _i, _i, _P(_f)]),
     "sarx_csa_plan_create": (_i, [_vp, _i, _i, _P(RadarParams), C.c_uint, _P(_vp)]),

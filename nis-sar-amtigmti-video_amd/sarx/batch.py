@@ -255,6 +255,7 @@ class TwoChannelBatch:
                   "outs": {k: ctx.alloc(px * 4) for k in ("ati_phase", "slc1_mag", "dpca_mag")},
                   "masked": ctx.alloc(px * 4), "d_max": ctx.alloc(_ffi.MAX_SLOT_BYTES)}
             self._lane_state.append(st)
+        self.lane_ids = ctx.concurrent_lanes(self.lanes)       # lanes that really run side by side (probed once per context)
         self._cur = 0
         # the 5 % mask inside the ATI launch: channel 1's focus leaves max|slc1| in d_max while it writes the image
         # (sarx_csa_plan_set_max_slot), so no further pass over the phase and magnitude planes is needed
@@ -289,7 +290,7 @@ class TwoChannelBatch:
     def use_lane(self, lane):
         """Later focus_frame calls run on compute lane `lane` with that lane's plan and buffers."""
         self._cur = int(lane) % self.lanes
-        self.ctx.select_lane(self._cur)
+        self.ctx.select_lane(self.lane_ids[self._cur])
 
     # -- one frame -------------------------------------------------------------------------------------------
     def synth_frame(self, f, slot):

@@ -141,6 +141,7 @@ class Context:
         self.device_id = int(device_id)
         self._live = {}
         self._plans = weakref.WeakSet()
+        self._lane_sets, self._lane_ratios = {}, {}
         self._scratch = {}             # (tag, lane) -> DeviceBuffer
         self._lane = 0
         self._pinned_free = {}         # nbytes -> [ptr, ...]
@@ -241,6 +242,36 @@ class Context:
         """Persistent range launches size their grid for `cus` compute units (0 = all): with frames in flight the rest of the
         chip stays available to the other lane's azimuth launches (sarx_set_range_cus)."""
         check(self.lib.sarx_set_range_cus(self.h, int(cus)), self.h)
+
+    def probe_lanes(self, a, b, us=300):
+        """together / alone time of two small launches on lanes a and b: ~1 = the lanes run side by side, ~2 = they share a hardware
+        queue and take turns (sarx_probe_lanes)."""
+        r = C.c_double()
+        check(self.lib.sarx_probe_lanes(self.h, int(a), int(b), int(us), C.byref(r)), self.h)
+        return r.value
+
+    def concurrent_lanes(self, k=2):
+        """k lane numbers (lane 0 first) that run side by side, for frames in flight: HIP may put two of a context's streams on one
+        hardware queue, and frames in flight on such a pair gain nothing.  Probed once per context (a few milliseconds)."""
+        k = max(1, min(int(k), 4))
+        if k == 1:
+            return [0]
+        if self._lane_sets.get(k) is None:
+            chosen, ratios = [0], {}
+            for cand in (1, 2, 3):
+                if len(chosen) == k:
+                    break
+                ratios[cand] = max(self.probe_lanes(x, cand) for x in chosen)
+                if ratios[cand] < 1.5:
+                    chosen.append(cand)
+            for cand in sorted(ratios, key=ratios.get):          # not enough independent lanes: take the least bad ones
+                if len(chosen) == k:
+                    break
+                if cand not in chosen:
+                    chosen.append(cand)
+            self._lane_sets[k] = chosen
+            self._lane_ratios = ratios
+        return list(self._lane_sets[k])
 
     def lanes_join(self):
         """On the device: every lane waits for everything enqueued so far on every lane."""
@@ -464,13 +495,14 @@ class FocusLanes:
             lanes = 2 if int(n_az) * int(n_rg) >= 4096 * 4096 else 1
         self.ctx, self.lanes, self.range_cus = ctx, max(1, min(int(lanes), 4)), int(range_cus)
         self.plans = [CsaPlan(ctx, n_az, n_rg, *focus_args, flags=flags) for _ in range(self.lanes)]
+        self.lane_ids = ctx.concurrent_lanes(self.lanes)       # lanes that really run side by side (probed once per context)
         self._i = 0
 
     def focus_dev(self, d_phist, d_image):
         lane = self._i % self.lanes
         self._i += 1
         if self.lanes > 1:
-            self.ctx.select_lane(lane)
+            self.ctx.select_lane(self.lane_ids[lane])
             self.ctx.set_range_cus(self.range_cus)     # the persistent range launch leaves CUs to the other lane's azimuth tiles
         self.plans[lane].focus_dev(d_phist, d_image)
         return lane

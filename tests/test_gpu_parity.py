@@ -580,6 +580,23 @@ def test_lanes_and_range_cu_share_leave_results_unchanged(sx, ctx):
         b.release()
 
 
+def test_lane_probe_and_choice(sx):
+    """sarx_probe_lanes: two lanes either run side by side (ratio ~1) or share a hardware queue and take turns (~2);
+    Context.concurrent_lanes picks lanes of the first kind for frames in flight, lane 0 first, and remembers its choice."""
+    ctx = sx.Context(0)
+    ratios = {(a, b): ctx.probe_lanes(a, b) for a in range(4) for b in range(a + 1, 4)}
+    assert all(0.7 < r < 2.6 for r in ratios.values()), ratios
+    two = ctx.concurrent_lanes(2)
+    assert two[0] == 0 and len(two) == 2 and two[1] in (1, 2, 3)
+    if min(ratios[(0, b)] for b in (1, 2, 3)) < 1.4:            # some lane runs beside lane 0: that is the one chosen
+        assert ratios[(0, two[1])] < 1.6, (two, ratios)
+    assert ctx.concurrent_lanes(2) == two and ctx.concurrent_lanes(1) == [0]
+    assert len(set(ctx.concurrent_lanes(3))) == 3
+    with pytest.raises(sx.SarxError):
+        ctx.probe_lanes(1, 1)
+    ctx.close()
+
+
 def test_focus_lanes_helper(sx, ctx):
     """sarx.FocusLanes: a frame loop with two frames in flight returns every frame's image bit-identical to CsaPlan.focus_dev,
     alternates lanes, and leaves lane 0 selected with the range launch's CU share reset after finish()."""
