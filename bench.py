@@ -58,18 +58,25 @@ def parse_args(argv=None):
     ap.add_argument("--no-batch", action="store_true", help="skip the batch64 block (BASELINE config 5)")
     ap.add_argument("--batch-frames", type=int, default=64)
     ap.add_argument("--batch-size", type=int, default=8192)
-    ap.add_argument("--stack", choices=("multilook", "magnitude", "products", "both", "all"), default="multilook",
+    ap.add_argument("--stack", choices=("multilook", "magnitude", "products", "both", "all", "default"), default="default",
                     help="batch64 stack slot: 16x16 multilook (1 MiB/frame at 8192^2; headline), full-resolution "
                          "magnitude (256 MiB/frame: loads xGMI), products (masked ATI phase, |slc1|, DPCA magnitude: 768 MiB/frame, "
-                         "SURVEY.md 8(e)'s product stack), both = multilook + magnitude, all = the three one after the other")
+                         "SURVEY.md 8(e)'s product stack), both = multilook + magnitude, all = the three one after the other; "
+                         "default = multilook + products")
     ap.add_argument("--batch-scene", choices=("noise", "c3"), default="noise",
                     help="batch64 content: device noise (bandwidth does not depend on content) or SURVEY.md 8(d) C5's scene - the C3 point-target "
                          "scene with its movers advanced by f * 0.1 s per frame, synthesised on the device before the clock starts")
     ap.add_argument("--batch-reps", type=int, default=3, help="timed repetitions of the batch64 block (the median is reported; keeps the GPU busy long enough to be sampled)")
-    ap.add_argument("--config3", action="store_true",
-                    help="add a `config3_two_channel` block: BASELINE config 3 (two-channel --batch-size^2 scene: 2 x CSA focus + ATI/DPCA + "
-                         "5 %% mask through sarx.focus_ati_dpca, device-resident) with its own cpu_baseline (oracle: 2 x focus + the "
-                         "sar_ati_dcpa_sim_csa.py:414-419,447-449 expressions)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `config2_4096` / `config3_two_channel` blocks (BASELINE configs 2 and 3; GPU legs of < 0.1 s each, on by default at N = 1)")
+    ap.add_argument("--config3-cpu", action="store_true",
+                    help="give the `config3_two_channel` block its own cpu_baseline (oracle: 2 x focus + the sar_ati_dcpa_sim_csa.py:414-419,447-449 "
+                         "expressions; ~1 min)")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="RCCL must come up on every rank or every rank exits non-zero together; this is already the behaviour whenever the ranks sit on "
+                         "distinct devices (N > 1 and at least N GPUs visible)")
+    ap.add_argument("--allow-host-transport", action="store_true",
+                    help="permit the gloo-through-host-memory fallback even with one GPU per rank (rehearsals only: such a line is not an xGMI measurement)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank reports (rank, local rank, world) and exits before touching the GPU")
     return ap.parse_args(argv)
@@ -90,26 +97,92 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(size, workers=1, scaled=True):
-    """Oracle ("port") timed on this box's host cores.  scaled: an 8192^2 sample on one thread (how the reference's
-    NumPy runs), scaled x4 by sample count; not scaled: the real size x size frame, row-blocked, `workers` threads."""
+def rccl_required(world, n_dev, a):
+    """One GPU per rank (the driver's scaling run: N > 1 ranks, at least N devices visible) or --require-rccl: a line whose slots
+    travelled through host memory would be a host-memory number under an xGMI heading, so RCCL must come up.  Ranks outnumbering
+    GPUs (a rehearsal on one card) and --allow-host-transport may fall back to gloo, and the line says so."""
+    if world <= 1:
+        return False
+    return bool(a.require_rccl or (n_dev >= world and not a.allow_host_transport))
+
+
+def exit_together_without_rccl(dist, log):
+    """RCCL is required and did not come up: every rank leaves with code 3.  `use_rccl` is the result of a MIN-reduce over all ranks
+    (sarx.batch.agree_on_rccl), so every rank takes this branch or none does; the barrier keeps the process group alive until all have."""
+    log("RCCL did not come up on every rank and this run requires it (one GPU per rank, or --require-rccl): exiting 3 on every rank")
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(3)
+
+
+class _RehearsalCtx:
+    """--dry-run only (no GPU): stands in for sarx.Context in agree_on_rccl so the launcher tests can rehearse the RCCL policy with
+    gloo ranks; SARX_BENCH_REHEARSE_RCCL_FAIL lists the ranks whose communicator 'fails' (-1: the unique id itself fails)."""
+
+    def __init__(self, rank, failing):
+        self.rank, self.failing, self.h = rank, failing, None
+        self.lib = self
+
+    def comm_unique_id(self):
+        if -1 in self.failing:
+            raise RuntimeError("rehearsal: ncclGetUniqueId fails")
+        return b"\0" * 128
+
+    def comm_init(self, uid, world, rank):
+        if rank in self.failing:
+            raise RuntimeError(f"rehearsal: ncclCommInitRank fails on rank {rank}")
+
+    def sarx_comm_destroy(self, h):
+        return 0
+
+
+def noise_frame(n, seed=0):
+    """n x n complex64 Gaussian noise on the host, built in pieces (no n x n float64 temporaries)."""
     import numpy as np
-    from oracle import csa_oracle as orc
-    n = min(size, 8192) if scaled else size
-    k = orc.scaled_radar(n, n)
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     raw = np.empty((n, n), dtype=np.complex64)
-    for i0 in range(0, n, 1024):                                     # in pieces: no n x n float64 temporaries
+    for i0 in range(0, n, 1024):
         blk = rng.standard_normal((min(1024, n - i0), n, 2), dtype=np.float32)
         raw[i0:i0 + blk.shape[0]] = blk[..., 0] + 1j * blk[..., 1]
+    return raw
+
+
+def cpu_baseline(size, workers=1, scaled=True, frame=None, keep_image=False):
+    """Oracle ("port") timed on this box's host cores.  scaled: an 8192^2 sample on one thread (how the reference's
+    NumPy runs), scaled x4 by sample count; not scaled: the real size x size frame, row-blocked, `workers` threads.
+    frame: (host echo, radar args) of the frame the GPU legs focused - the CPU leg then runs on THAT frame and, with
+    keep_image, its image ([n_az x n_rg] complex128) is returned beside the block for the parity figure."""
+    from oracle import csa_oracle as orc
+    if frame is not None:
+        raw, args = frame
+        n = raw.shape[0]
+    else:
+        n = min(size, 8192) if scaled else size
+        raw, args = noise_frame(n), orc.focus_args(orc.scaled_radar(n, n))
     t = time.perf_counter()
-    orc.sar_focus_csa_lean(raw, *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)
+    img = orc.sar_focus_csa_lean(raw, *args, workers=workers, block=64 if workers > 1 else 512)[0]
     best = time.perf_counter() - t
     scale = (size / n) ** 2                      # samples per full frame / samples in the sample
     how = (f"scaled x{scale:.0f} by sample count to {size}x{size}" if scale != 1 else "the full frame, not scaled")
-    return {"value": 1.0 / (best * scale), "unit": "frames/s", "cores": workers, "kind": "port",
-            "sample": f"{n}x{n} complex64 noise frame, oracle/csa_oracle.sar_focus_csa_lean (NumPy/scipy.fft, "
-                      f"{workers} thread(s) of {os.cpu_count()}), {best:.2f} s, {how}"}
+    what = ("the frame the GPU legs focused (lane 0's echo, downloaded once)" if frame is not None else "complex64 noise frame")
+    blk = {"value": 1.0 / (best * scale), "unit": "frames/s", "cores": workers, "kind": "port",
+           "sample": f"{n}x{n} {what}, oracle/csa_oracle.sar_focus_csa_lean (NumPy/scipy.fft, "
+                     f"{workers} thread(s) of {os.cpu_count()}), {best:.2f} s, {how}"}
+    return (blk, img.T) if keep_image else blk
+
+
+def parity_figures(gpu_img, cpu_img, rows=256):
+    """Relative L2 of the GPU image against the oracle's complex128 image of the same echo, |img| and complex
+    (north_star's bar: <= 1e-4), accumulated row block by row block in float64 - no full-size temporaries."""
+    import numpy as np
+    num_c = num_m = den = 0.0
+    for i0 in range(0, gpu_img.shape[0], rows):
+        g = gpu_img[i0:i0 + rows].astype(np.complex128)
+        c = cpu_img[i0:i0 + rows]
+        num_c += float(np.sum(np.abs(g - c) ** 2))
+        num_m += float(np.sum((np.abs(g) - np.abs(c)) ** 2))
+        den += float(np.sum(np.abs(c) ** 2))
+    return {"rel_l2_mag": (num_m / den) ** 0.5, "rel_l2_complex": (num_c / den) ** 0.5, "bar": 1e-4}
 
 
 def cpu_baseline_two_channel(n_full, workers, n_sample):
@@ -118,14 +191,7 @@ def cpu_baseline_two_channel(n_full, workers, n_sample):
     import numpy as np
     from oracle import csa_oracle as orc
     k = orc.scaled_radar(n_sample, n_sample)
-    rng = np.random.default_rng(0)
-    chans = []
-    for _ in range(2):
-        raw = np.empty((n_sample, n_sample), dtype=np.complex64)
-        for i0 in range(0, n_sample, 1024):
-            blk = rng.standard_normal((min(1024, n_sample - i0), n_sample, 2), dtype=np.float32)
-            raw[i0:i0 + blk.shape[0]] = blk[..., 0] + 1j * blk[..., 1]
-        chans.append(raw)
+    chans = [noise_frame(n_sample, seed) for seed in (0, 1)]
     t = time.perf_counter()
     s1 = orc.sar_focus_csa_lean(chans[0], *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)[0]
     s2 = orc.sar_focus_csa_lean(chans[1], *orc.focus_args(k), workers=workers, block=64 if workers > 1 else 512)[0]
@@ -142,6 +208,41 @@ def cpu_baseline_two_channel(n_full, workers, n_sample):
             "sample": f"two-channel {n_sample}x{n_sample} complex64 noise frame: oracle focus x2 {t_focus:.2f} s ({workers} thread(s) of "
                       f"{os.cpu_count()}) + ATI/DPCA/mask expressions (NumPy, 1 thread) {t_prod:.2f} s" +
                       (f", scaled x{scale:.0f} by sample count to {n_full}x{n_full}" if scale != 1 else ", the full frame")}
+
+
+def run_single_channel(sarx, ctx, n, steps=200, lanes=2):
+    """BASELINE config 2 (4096^2 single-channel CSA focus on one GPU), echo resident in HBM, the headline region's own form: frame s on
+    lane s % lanes, every lane with its own plan, echo and image."""
+    from sarx import _ffi, radar
+    plans = [sarx.CsaPlan(ctx, n, n, *radar.focus_args(n), flags=_ffi.FUSE_RANGE) for _ in range(lanes)]
+    bufs = [(ctx.alloc(n * n * 8), ctx.alloc(n * n * 8)) for _ in range(lanes)]
+    for i, (d_in, _) in enumerate(bufs):
+        ctx.fill_noise(d_in, n * n, 77 + i)
+    ids = ctx.concurrent_lanes(lanes)
+    try:
+        def run(count):
+            for s in range(count):
+                ctx.select_lane(ids[s % lanes])
+                plans[s % lanes].focus_dev(*bufs[s % lanes])
+        run(2 * lanes)
+        ctx.sync()
+        t0 = time.perf_counter()
+        run(steps)
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        ctx.select_lane(0)
+    import numpy as np
+    probe = bufs[0][1].download(np.complex64, (2, n))
+    assert np.isfinite(probe).all() and np.abs(probe).max() > 0
+    for x in plans:
+        x.close()
+    for pair in bufs:
+        for b in pair:
+            b.release()
+    return {"metric": "focused SAR frames/sec (CSA focus, complex64)", "value": 1e3 / ms, "unit": "frames/s", "ms_per_frame": ms, "steps": steps,
+            "workload": f"{n}x{n} complex64 single-channel CSA focus, echo resident in HBM (BASELINE config 2), {lanes} frames in flight",
+            "frame_bandwidth_frac_of_peak_algorithmic": 64.0 * n * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def run_config3(sarx, ctx, n, frames=10, cpu=True):
@@ -276,13 +377,27 @@ def main():
         me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(),
               "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         ranks = [me]
+        rehearsal = None
         if dist is not None:
             ranks = [None] * world
             dist.all_gather_object(ranks, me)
+            fail_env = os.environ.get("SARX_BENCH_REHEARSE_RCCL_FAIL")
+            if fail_env is not None:          # rehearse the collective bring-up and its policy (SARX_BENCH_REHEARSE_DEVICES = visible GPUs)
+                from sarx.batch import agree_on_rccl
+                log = lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)
+                failing = {int(x) for x in fail_env.split(",") if x.strip()}
+                ok = agree_on_rccl(_RehearsalCtx(rank, failing), world, rank, dist, log)
+                n_dev = int(os.environ.get("SARX_BENCH_REHEARSE_DEVICES", str(world)))
+                if not ok and rccl_required(world, n_dev, a):
+                    exit_together_without_rccl(dist, log)
+                rehearsal = {"rccl_up": ok, "required": rccl_required(world, n_dev, a), "devices": n_dev}
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            emit({"dry_run": True, "n_gpus": world, "ranks": ranks})
+            out = {"dry_run": True, "n_gpus": world, "ranks": ranks}
+            if rehearsal is not None:
+                out["rccl_rehearsal"] = rehearsal
+            emit(out)
         return
 
     import numpy as np
@@ -315,9 +430,12 @@ def main():
     slot_bytes = (n // LOOKS) * (n // LOOKS) * 4
     force_comm = os.environ.get("SARX_BENCH_FORCE_COMM") == "1"     # exercise the gather path on one GPU
     d_recv = None
+    ranks_devices = None
     if world > 1 or force_comm:
         log = lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)
         use_rccl = agree_on_rccl(ctx, world, rank, dist, log)
+        if not use_rccl and rccl_required(world, n_dev, a):
+            exit_together_without_rccl(dist, log)
         try:
             rccl = sarx.Context.rccl_info()
         except sarx.SarxError as exc:
@@ -328,6 +446,18 @@ def main():
             host_comm = TorchStackComm() if dist is not None else None
             collective = "gloo all-gather through host memory (RCCL did not come up on every rank: see stderr)"
         d_recv = ctx.alloc(slot_bytes * world * 2)                # two round blocks, alternating
+        me = {"rank": rank, "local_rank": local_rank, "device": ctx.device_id, "pid": os.getpid()}
+        ranks_devices = [me]
+        if dist is not None:
+            ranks_devices = [None] * world
+            dist.all_gather_object(ranks_devices, me)
+
+    # execution span of every timed step's fused range launch from in-kernel clock stamps (sarx_csa_plan_stamp_range): with frames in
+    # flight an event pair around the launch also contains its queueing behind the other lane's kernels
+    N_STAMP = 128
+    stamps_on = (not a.unfused) and n == 16384
+    d_stamp = ctx.alloc(N_STAMP * 16)
+    stamp_init = np.tile(np.array([2**64 - 1, 0], dtype=np.uint64), N_STAMP)
 
     def step(s, mark, lanes=L):
         lane = s % lanes
@@ -338,6 +468,7 @@ def main():
             plan.mark_range(2 * s, 2 * s + 1)
         else:
             plan.mark_range(-1, -1)
+        plan.stamp_range(d_stamp.ptr + 16 * s if (mark and stamps_on and s < N_STAMP) else None)
         if d_recv is None:
             plan.focus_dev(d_in, d_img)
             return
@@ -363,14 +494,24 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def stamp_ms(count):
+        """mean execution span (ms) of the stamped launches 0 .. count-1; None when nothing was stamped"""
+        if not stamps_on or count < 1:
+            return None
+        st = d_stamp.download(np.uint64, (N_STAMP, 2))[:min(count, N_STAMP)]
+        ok = st[:, 1] > 0
+        return float(np.mean((st[ok, 1] - st[ok, 0]).astype(np.float64)) * 1e-5) if ok.any() else None      # 100 MHz ticks -> ms
+
     for s in range(W):
         step(s, False)
+    d_stamp.upload(stamp_init)
     barrier()
     t0 = time.perf_counter()
     for s in range(K):
         step(s, True)
     barrier()
     dt = time.perf_counter() - t0
+    rg_span_ms = stamp_ms(K)
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
@@ -390,6 +531,7 @@ def main():
         Ks = min(K, 40)
         for s in range(2):
             step(s, False, lanes=1)
+        d_stamp.upload(stamp_init)
         barrier()
         t1 = time.perf_counter()
         for s in range(Ks):
@@ -403,9 +545,17 @@ def main():
             dt1 = float(t.item())
         rg1 = sum(ctx.elapsed_ms(2 * s, 2 * s + 1) for s in range(Ks)) / Ks
         solo = {"steps": Ks, "ms_per_step": dt1 / Ks * 1e3, "value": world * Ks / dt1, "range_launch_ms": rg1 / launches,
-                "range_achieved_GBps": alg_bytes / (rg1 * 1e-3) / 1e9}
+                "range_achieved_GBps": alg_bytes / (rg1 * 1e-3) / 1e9, "range_span_ms": stamp_ms(Ks)}
+    for x in plans:
+        x.mark_range(-1, -1)
+        x.stamp_range(None)
     ctx.select_lane(0)
     ctx.set_range_cus(0)
+
+    # the frame lane 0 focused, for the parity figure of the line: its echo and its image, downloaded once (after every timed region)
+    host_frame = None
+    if rank == 0 and world == 1 and not a.no_cpu and not a.cpu_sample:
+        host_frame = (d_ins[0].download(np.complex64, (n, n)), d_imgs[0].download(np.complex64, (n, n)))
 
     probe = d_img.download(np.complex64, (4, n))
     assert np.isfinite(probe).all() and np.abs(probe).max() > 0, "focused image is not finite / all zero"
@@ -484,6 +634,44 @@ def main():
         traffic, traffic_src = replay("range_fused")
         traffic_p2, traffic_p2_src = replay("range_wp_kernel<2>")
 
+    fused_wl = (not a.unfused) and n == 16384
+    kernel_name = ("range_fused_wl_kernel (FFT.Phi2.IFFT.Phi3, one HBM round trip)" if fused_wl else
+                   "range_pass_kernel<fused>" if not a.unfused else "range_pass_v2_kernel<FFT+Phi2>, <IFFT+Phi3>")
+    # vector instructions per launch of the fused kernel, REPLAYED from the SQ_INSTS_VALU pass kept under profiles/ (it depends on the
+    # code, not on the run); peak issue = one wave64 instruction per 2 cycles per SIMD-32, 4 SIMDs x CUs, at the 2.4 GHz maximum clock
+    valu_insts, valu_src = None, None
+    if fused_wl:
+        for name in ("r05_pmc_range_kernels.json", "r02_pmc_range_kernels.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    kk = json.load(fh)["kernels"]
+                valu_insts = next(v["counters"]["SQ_INSTS_VALU"] for k2, v in kk.items() if "range_fused" in k2 and "SQ_INSTS_VALU" in v.get("counters", {}))
+                valu_src = f"SQ_INSTS_VALU per launch replayed from profiles/{name} (separate rocprofv3 --pmc pass)"
+                break
+            except (OSError, StopIteration, KeyError, ValueError):
+                continue
+    valu_peak = 256 * 4 * 2.4e9 / 2.0
+
+    def roofline_block(ms, how):
+        """achieved = algorithmic bytes per launch / launch duration.  `bound` says what the counters say limits the kernel."""
+        ach = 16.0 * n * n / (ms * 1e-3) / 1e9
+        blk = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+               "traffic": traffic, "traffic_source": traffic_src, "launch_ms": ms, "timed_with": how,
+               "algorithmic_bytes_per_launch": 16.0 * n * n}
+        if fused_wl:
+            # profiles/r02_pmc_range_kernels.json: a wave issues vector work 43 % of its lifetime, 28 % stalled at issue, 24 % at waits /
+            # barriers, two waves per SIMD (233 VGPRs), 1.001 x the algorithmic bytes: the launch is limited by dependent vector issue
+            # at that occupancy, not by HBM - `frac` stays the HBM fraction the metric asks for, valu_issue is the fraction of its own bound
+            blk["bound"] = "valu-issue"
+            blk["bound_note"] = ("instruction issue at two waves per SIMD (233 VGPRs, one 136 KiB-LDS workgroup per CU), not HBM: 1.001 x algorithmic "
+                                 "bytes moved at about half the bandwidth; achieved / peak / frac are the HBM figures BASELINE's metric asks for")
+            if valu_insts:
+                rate = valu_insts / (ms * 1e-3)
+                blk["valu_issue"] = {"wave_instructions_per_launch": valu_insts, "achieved_per_s": rate, "peak_per_s": valu_peak,
+                                     "frac": rate / valu_peak, "source": valu_src,
+                                     "peak_note": "256 CUs x 4 SIMD-32 x one wave64 instruction per 2 cycles at 2.4 GHz"}
+        return blk
+
     line = None
     if rank == 0:
         line = {
@@ -491,19 +679,15 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "c64 (phase arguments f64)", "data": "synthetic",
             "config": {"workload": f"{n}x{n} complex64 single-channel CSA focus, echo resident in HBM",
-                       "frames_per_step_per_gpu": 1, "frames_in_flight_per_gpu": L, "range_launch_cus": range_cus if L > 1 else "all",
+                       "frames_per_step_per_gpu": 1,
+                       # the host-transport fallback downloads every slot with a blocking copy that waits for every lane: one frame in flight in effect
+                       "frames_in_flight_per_gpu": L if (use_rccl or d_recv is None) else 1, "range_launch_cus": range_cus if L > 1 else "all",
                        "lanes": lane_ids, "lane_probe_ratio": {str(k2): round(v2, 2) for k2, v2 in ctx._lane_ratios.items()},
                        "range_passes": "fused 2+3" if not a.unfused else "separate",
                        "image_layout": "[n_az x n_rg]; img.T returned as a view like the reference",
                        "parallelism": f"frames sharded 1/GPU x{world}" +
                                       (f"; 16x16 multilook slot fused into the focus + {collective} per step" if collective else "")},
-            "roofline": {"bound": "hbm", "kernel": ("range_fused_wl_kernel (FFT.Phi2.IFFT.Phi3, one HBM round trip)"
-                                                    if (not a.unfused and n == 16384) else
-                                                    "range_pass_kernel<fused>" if not a.unfused else
-                                                    "range_pass_v2_kernel<FFT+Phi2>, <IFFT+Phi3>"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": rg_ms / launches,
-                         "algorithmic_bytes_per_launch": 16.0 * n * n},
+            "roofline": roofline_block(rg_span_ms if rg_span_ms else rg_ms / launches, "in-kernel clock stamps" if rg_span_ms else "HIP events"),
         }
         moved = (5 if (n > 128 and not a.unfused) else 6 if n > 128 else 3 if not a.unfused else 4) * 16.0 * n * n   # HBM round trips of the image per frame
         line["frame_bandwidth"] = {
@@ -513,23 +697,31 @@ def main():
             "note": "whole frame per GPU over the timed region: SURVEY.md 8(d)'s four passes x 16 B/sample (algorithmic) and the image's actual HBM "
                     "round trips (two launches per two-step azimuth transform + the fused range launch)"}
         line["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SARX_")}      # kernel-form switches in effect
+        line["roofline"]["measured_in"] = (
+            f"the HEADLINE region of this run ({L} frame(s) in flight, range grid sized for {range_cus if L > 1 else 'all'} CUs): " +
+            ("execution span of every timed step's launch from in-kernel clock stamps (first workgroup's start to last workgroup's end, "
+             "s_memrealtime), i.e. without the time the launch queues behind the other lane's kernels; rocprofv3 --kernel-trace --stats of the "
+             "same command: profiles/r05_*_bench_kernel_stats.csv" if rg_span_ms else
+             "HIP events recorded on the launch's own stream around every timed step's range launch(es)"))
+        line["roofline"]["launch_ms_between_events"] = rg_ms / launches
         if solo is not None:
-            # The roofline describes the KERNEL: it is taken from the one-frame-in-flight leg, where the launch has the GPU to itself and
-            # an event pair around it measures its execution (and agrees with rocprofv3 --kernel-trace of `bench.py --in-flight 1`).
-            # In the headline region launches of two frames share the GPU: an event pair around one of them also contains the time its
-            # workgroups wait for CUs the other frame's launches hold, which is not a property of the kernel - kept as roofline_shared.
-            shared = dict(line["roofline"])
-            shared["note"] = (f"HIP events around the range launch of every step of the HEADLINE region, {L} frames in flight: queueing behind and "
-                              "sharing with the other frame's launches included (rocprofv3 of the default command sees 1.3-1.4 ms of execution)")
-            line["roofline"].update(achieved=solo["range_achieved_GBps"], frac=solo["range_achieved_GBps"] / HBM_PEAK_GBS,
-                                    launch_ms=solo["range_launch_ms"], measured_in="the one_frame_in_flight leg of this run (lane 0 only, "
-                                    f"{solo['steps']} steps between barriers): HIP events around every range launch, the kernel alone on the GPU; "
-                                    "rocprofv3 summary of the same: profiles/r04_p_bench_inflight1_kernel_stats.csv (bench.py --in-flight 1)")
-            line["roofline_shared"] = shared
+            # the same kernel with the GPU to itself: the one_frame_in_flight leg (lane 0 only, grid sized for every CU), HIP events around
+            # every launch - the kernel's own figure, kept beside the headline configuration's
+            alone_ms = solo["range_launch_ms"]
+            line["roofline_kernel_alone"] = roofline_block(alone_ms, "HIP events")
+            line["roofline_kernel_alone"]["measured_in"] = (
+                f"the one_frame_in_flight leg of this run (lane 0 only, {solo['steps']} steps between barriers, grid sized for all CUs): HIP events "
+                "around every range launch, the kernel alone on the GPU; rocprofv3 summary of the same: profiles/r05_*_bench_inflight1_kernel_stats.csv "
+                "(bench.py --in-flight 1)" + (f"; in-kernel stamps of the same launches: {solo['range_span_ms']:.4f} ms" if solo.get("range_span_ms") else ""))
             line["one_frame_in_flight"] = {"ms_per_step": solo["ms_per_step"], "value": solo["value"], "unit": "frames/s", "steps": solo["steps"],
                                            "note": "the same steps on lane 0 only, timed after the headline region: one frame's latency"}
         if collective:
-            line["collective"] = {"transport": collective, "ranks": world, "rccl": rccl}
+            line["collective"] = {"transport": collective, "ranks": world, "rccl": rccl, "rccl_ranks": world if use_rccl else 0,
+                                  "rank_devices": ranks_devices,
+                                  "stack": {"name": f"multilook {LOOKS}x{LOOKS} of |img|^2 (one {slot_bytes / 2**20:.0f} MiB slot per frame, emitted by the focus)",
+                                            "gather_bytes_per_rank_per_step": slot_bytes,
+                                            "gather_s_per_step_at_one_xgmi_link": slot_bytes / (XGMI_LINK_GBS * 1e9),
+                                            "link_bound_at_8_gpus": bool(slot_bytes / (XGMI_LINK_GBS * 1e9) > dt / K)}}
             # false = RCCL did not come up on every rank and the slots travelled through host memory (a rehearsal on fewer devices
             # than ranks, or a broken node): such a line is NOT an xGMI scaling measurement
             line["collective_ok"] = bool(use_rccl)
@@ -559,30 +751,57 @@ def main():
         x.release()
     if d_recv is not None:
         d_recv.release()
+    d_stamp.release()
 
+    # ---- the other GPU legs, back to back, before any CPU leg (the driver's GPU-busy sampler then sees one busy stretch) ----------
     if not a.no_batch:
-        stacks = {"both": ("multilook", "magnitude"), "all": ("multilook", "magnitude", "products")}.get(a.stack, (a.stack,))
+        stacks = {"both": ("multilook", "magnitude"), "all": ("multilook", "magnitude", "products"),
+                  "default": ("multilook", "products")}.get(a.stack, (a.stack,))
         for st in stacks:
             blk = run_batch64(sarx, ctx, a, world, rank, dist, use_rccl, host_comm, barrier, st)
             if rank == 0:
                 blk["collective"] = collective or "none (one rank)"
                 line["batch64" if st == "multilook" else "batch64_" + st] = blk
+    if rank == 0 and world == 1 and not a.no_configs:
+        if n != 4096:
+            line["config2_4096"] = run_single_channel(sarx, ctx, 4096, steps=200)         # BASELINE config 2
+        line["config3_two_channel"] = run_config3(sarx, ctx, a.batch_size, frames=20, cpu=False)   # BASELINE config 3
 
-    if rank == 0 and world == 1 and a.config3:
-        line["config3_two_channel"] = run_config3(sarx, ctx, a.batch_size, cpu=not a.no_cpu)
+    # ---- CPU legs (rank 0 only; never inside a timed region) ---------------------------------------------------------------------
     if rank == 0:
         if not a.no_cpu:
             if world == 1:
-                # one thread (how the reference's NumPy runs) on the REAL frame, row-blocked lean path (BASELINE.md 4.3): ~30 s at 16384^2
-                line["cpu_baseline"] = cpu_baseline(n, workers=1, scaled=a.cpu_sample)
                 mt = min(os.cpu_count() or 1, 32)
+                frame = (host_frame[0], radar.focus_args(n)) if host_frame is not None else None
                 if mt > 1:                          # the all-core figure on the real frame next to the reference-style single thread
-                    line["cpu_baseline_threads"] = cpu_baseline(n, workers=mt, scaled=False)
+                    blk, img = cpu_baseline(n, workers=mt, scaled=False, frame=frame, keep_image=True)
+                    line["cpu_baseline_threads"] = blk
+                    if host_frame is not None:
+                        line["parity_threads"] = parity_figures(host_frame[1], img)
+                    del img
+                # one thread (how the reference's NumPy runs) on the REAL frame, row-blocked lean path (BASELINE.md 4.3): ~30 s at 16384^2
+                blk, img = cpu_baseline(n, workers=1, scaled=a.cpu_sample, frame=None if a.cpu_sample else frame, keep_image=True)
+                line["cpu_baseline"] = blk
+                if host_frame is not None:
+                    # north_star's bar (1): the timed frame itself, GPU image against the oracle's complex128 focus of the same echo
+                    line["parity"] = parity_figures(host_frame[1], img)
+                    line["parity"]["what"] = (f"lane 0's {n}x{n} frame of the timed region: GPU image (complex64, downloaded once) against "
+                                              "oracle/csa_oracle.sar_focus_csa_lean of the same downloaded echo (complex128, the cpu_baseline leg's own "
+                                              "output), relative L2 over all samples")
+                    assert line["parity"]["rel_l2_mag"] <= 1e-4 and line["parity"]["rel_l2_complex"] <= 1e-4, line["parity"]
+                else:
+                    line["parity"] = None
+                del img
+                if a.config3_cpu and "config3_two_channel" in line:
+                    line["config3_two_channel"]["cpu_baseline"] = cpu_baseline_two_channel(a.batch_size, 1, min(a.batch_size, 4096))
+                    if mt > 1:
+                        line["config3_two_channel"]["cpu_baseline_threads"] = cpu_baseline_two_channel(a.batch_size, mt, a.batch_size)
             else:
                 # N > 1 lines carry it too (north_star: every N next to the NumPy CPU path): rank 0's host cores, one thread, the bounded
                 # sample, timed AFTER every GPU leg while the other ranks wait at the final barrier - it is not part of any timed region
                 line["cpu_baseline"] = cpu_baseline(n, workers=1, scaled=True)
                 line["cpu_baseline"]["sample"] += f"; timed on rank 0 of {world} after the GPU legs, the other ranks idle at the barrier"
+        line["leg_order"] = "GPU legs back to back first (headline, one frame in flight, passes, batch64 blocks, configs 2 and 3), CPU legs last"
         emit(line)
     if dist is not None:
         dist.barrier()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 204   /* 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
+#define SARX_VERSION 205   /* 205: sarx_csa_plan_stamp_range (execution span of the fused range launch from in-kernel clock stamps); 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -114,15 +114,15 @@ int sarx_sync(sarx_ctx* ctx);      /* waits for every lane and the comm stream *
  * this ctx (focus, passes, products, memset, events) go to that lane's stream.  The frames of a batch are independent
  * (sar_batch_sim.py:303-331), so consecutive frames may be enqueued on alternating lanes - each lane with its OWN plan and its
  * own buffers - and kernels of neighbouring frames then share the GPU: the issue-bound range launch of one frame beside the
- * bandwidth-bound azimuth launches of the next (16384^2: 4.39 -> 3.93 ms per frame with two frames in flight).  Results are
+ * bandwidth-bound azimuth launches of the next (16384^2: 4.25-4.37 -> 3.91-4.26 ms per frame with two frames in flight, box by box).  Results are
  * bit-identical to one lane.  sarx_lanes_join: on the device, every lane waits for everything enqueued so far on every lane.
  * Blocking host copies and sarx_sync wait for all lanes. */
 int sarx_select_lane(sarx_ctx* ctx, int lane);
 int sarx_lanes_join(sarx_ctx* ctx);
 /* With frames in flight the persistent fused range launch (16384-sample lines: one 136 KiB-LDS workgroup per CU, which no azimuth
  * tile can share a CU with) should leave part of the chip to the other lane's azimuth launches: its grid is sized for `cus`
- * compute units instead of all of them (0 = all, the default; 192 of 256 measured best with two lanes: 3.93-3.96 ms per 16384^2
- * frame on every box met, against 4.1-4.3 ms when both lanes ask for the whole chip).  Results do not depend on it. */
+ * compute units instead of all of them (0 = all, the default; 192 of 256 measured best with two lanes: 3.91-4.26 ms per 16384^2
+ * frame over thirteen boxes, against 3.93-4.34 ms when both lanes ask for the whole chip: profiles/r04_boxes_inflight2_vs_1.log).  Results do not depend on it. */
 int sarx_set_range_cus(sarx_ctx* ctx, int cus);
 /* Do lanes a and b run side by side?  HIP maps streams onto a few hardware queues; two lanes that share one take turns and frames in
  * flight on them gain nothing (4.6 against 4.0 ms per 16384^2 frame, profiles/r04_ai_lane_probe_boxes.log).  Two small launches (64
@@ -160,6 +160,13 @@ int sarx_csa_pass(sarx_plan* plan, int pass_id, const void* d_in, void* d_out);
 /* profiling hook: sarx_csa_focus_dev records ctx event slots around its range pass(es)
  * (the roofline kernel); pass -1, -1 to switch off */
 int sarx_csa_plan_mark_range(sarx_plan* plan, int slot_start, int slot_stop);
+/* profiling hook for launches that share the GPU (frames in flight on several lanes): while d_pair is set, the fused range launch of
+ * every sarx_csa_focus_dev of this plan (16384-sample plans: range_fused_wl_kernel; ignored otherwise) reduces {start of its first
+ * workgroup, end of its last workgroup} into d_pair[0] (atomic min) / d_pair[1] (atomic max), in ticks of the device's 100 MHz
+ * constant clock (s_memrealtime) - the launch's execution span, which an event pair on the stream cannot separate from the time the
+ * launch queues behind another lane's kernels.  The caller initialises d_pair to {UINT64_MAX, 0} and reads it after a sync; one
+ * pair per launch to be measured.  d_pair = NULL switches it off (the kernel then executes no stamp instruction). */
+int sarx_csa_plan_stamp_range(sarx_plan* plan, uint64_t* d_pair);
 /* VideoSAR stack slot fused into the focus: while d_slot is set, every sarx_csa_focus_dev of this plan also writes
  * d_slot[(n_az/looks) x (n_rg/looks)] fp32 = mean of |image|^2 over looks x looks blocks (what sarx_multilook_dev computes from the
  * finished image, sar_batch_sim.py:322's display stack) - the last azimuth launch emits row-wise partial sums and a small launch
@@ -349,7 +356,9 @@ int sarx_comm_unique_id(void* id_out /*[SARX_COMM_ID_BYTES]*/);
 int sarx_rccl_info(char* path, size_t path_len, int* version, int* header_version);
 int sarx_comm_init(sarx_ctx* ctx, const void* id, int n_ranks, int rank);
 /* recv[rank r] = send of rank r; bytes_per_rank multiple of 4; async on the ctx comm stream,
- * ordered after everything already enqueued on the compute stream */
+ * ordered after everything already enqueued on the CURRENT lane's compute stream (sarx_select_lane) - and on that lane only:
+ * a send buffer written on another lane must be gathered with that lane selected, or after sarx_lanes_join.  The same holds for
+ * sarx_allreduce_max_dev, and sarx_comm_fence_compute / sarx_comm_wait_mark make later work of the current lane (only) wait. */
 int sarx_allgather_dev(sarx_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 /* d_buf[i] = max over ranks of d_buf[i] (fp32, in place); same stream ordering as the gather.  The collective half of the
  * global display normalisation of a frame stack, g_max = max over all frames of max|frame| (sar_batch_sim.py:337-338):

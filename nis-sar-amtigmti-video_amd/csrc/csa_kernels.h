@@ -42,6 +42,10 @@ struct RangeArgs {
     // of the result the samples [conv_crop0, conv_crop0 + conv_out) go to the output line (leading dimension conv_out_ld)
     int conv_valid, conv_crop0, conv_out;
     size_t conv_in_ld, conv_out_ld;
+    // optional {first workgroup start, last workgroup end} of this launch in s_memrealtime ticks (100 MHz), reduced with
+    // atomic min / max by one lane per workgroup (sarx_csa_plan_stamp_range; range_fused_wl_kernel only): the launch's
+    // execution span while other launches share the GPU, which an event pair on the stream cannot separate from queueing
+    unsigned long long* stamp;
 };
 __host__ __device__ inline int range_row(const RangeArgs& a, int line) {
     return a.row_inner ? a.row0 + line % a.row_inner + (line / a.row_inner) * a.row_stride : line;

@@ -264,17 +264,27 @@ hipError_t launch_magnitude(const cf* in, float* out, size_t n, hipStream_t st) 
 
 // max |x| of an fp32 buffer folded into *out (non-negative floats order like their bit patterns, so one atomicMax on the
 // bits per wave): the per-rank half of the global display normalisation of a frame stack (sar_batch_sim.py:337-338)
+// The maximum is taken on the bit patterns (|x| has the sign bit clear, so the patterns order like the values and every NaN
+// orders above infinity): a NaN in the frame comes out as a NaN, as np.max(np.abs(fr)) does - fmaxf would drop it.
+// x may sit at any 4-byte alignment (a stack slot of odd pixel count): a scalar head up to the first 16-byte boundary.
 __global__ __launch_bounds__(256) void max_abs_f32_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
-    const size_t n4 = n / 4;
+    auto bits = [](float v) { return __float_as_uint(fabsf(v)); };
+    size_t head = ((16 - ((uintptr_t)x & 15)) & 15) / 4;          // floats before the first 16-byte boundary
+    if (head > n) head = n;
+    const float* __restrict__ xa = x + head;
+    const size_t na = n - head, n4 = na / 4;
     const size_t stride = (size_t)gridDim.x * 256;
-    float m = 0.f;
+    unsigned m = 0u;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const float4 a = reinterpret_cast<const float4*>(x)[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+        const float4 a = reinterpret_cast<const float4*>(xa)[i];
+        m = max(max(m, max(bits(a.x), bits(a.y))), max(bits(a.z), bits(a.w)));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) m = max(m, bits(x[threadIdx.x]));
+        if (threadIdx.x < (na & 3)) m = max(m, bits(xa[n4 * 4 + threadIdx.x]));
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0u) atomicMax(out, m);
 }
 hipError_t launch_max_abs_f32(const float* x, size_t n, float* out, hipStream_t st) {
     size_t b = (n / 4 + 255) / 256;

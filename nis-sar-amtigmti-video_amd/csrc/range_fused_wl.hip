@@ -83,6 +83,7 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
     using namespace wl;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);
+    if (a.stamp && threadIdx.x == 0) atomicMin(a.stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     const cf* __restrict__ tw = a.tw;                 // exp(-2 pi i m / 16384)
     const cf* __restrict__ tw_m = a.tw - N + M;       // the 1024 table sits at offset 1024 of the same array
 
@@ -168,6 +169,10 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
                 st16<false>(dst + 2 * t + n1 * M, make_float4(y0.x, y0.y, y1.x, y1.y));
             }
         }
+    }
+    if (a.stamp && threadIdx.x == 0) {                // after this wave's last stores have been acknowledged
+        __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
+        atomicMax(a.stamp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 

@@ -150,6 +150,7 @@ struct sarx_plan {
     float2 *h_in = nullptr, *h_out = nullptr;   // device staging for the *_host entry point
     uint64_t bytes = 0;
     int mark_start = -1, mark_stop = -1;   // ctx event slots recorded around the range pass(es)
+    unsigned long long* stamp = nullptr;   // sarx_csa_plan_stamp_range: {min start, max end} of the fused range launch (s_memrealtime ticks)
     GeneralCsa* gen = nullptr;             // chirp-z path for sizes that are not powers of two in [16, 16384]
 };
 
@@ -592,6 +593,13 @@ int sarx_csa_plan_mark_range(sarx_plan* p, int slot_start, int slot_stop) {
     return SARX_OK;
 }
 
+int sarx_csa_plan_stamp_range(sarx_plan* p, uint64_t* d_pair) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    if (((uintptr_t)d_pair) & 7) return fail(p->ctx, SARX_ERR_INVALID, "the stamp pair must be 8-byte aligned");
+    p->stamp = reinterpret_cast<unsigned long long*>(d_pair);
+    return SARX_OK;
+}
+
 int sarx_csa_plan_set_look_slot(sarx_plan* p, int looks, float* d_slot) {
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
     sarx_ctx* c = p->ctx;
@@ -908,6 +916,7 @@ int sarx_csa_focus_dev(sarx_plan* p, const void* d_phist, void* d_image) {
     if (p->mark_start >= 0) { HIPCHK(c, hipEventRecord(c->ev[p->mark_start], c->stream)); c->ev_set[p->mark_start] = true; }
     if (p->flags & SARX_FUSE_RANGE) {
         RangeArgs a = range_args(p, p->buf_b, p->buf_b);
+        a.stamp = p->stamp;
         HIPCHK(c, run_range(p, RG_FUSED, a));
     } else if (range_wp_supported(p->n_rg) && (c->range_impl == 0 || c->range_impl == 4)) {
         // two launches with the spectrum in permuted order between them (range_wp.hip): one workgroup-wide exchange each

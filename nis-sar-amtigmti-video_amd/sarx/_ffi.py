@@ -83,6 +83,7 @@ SIGNATURES = {
     "sarx_csa_focus_dev": (_i, [_vp, _vp, _vp]),
     "sarx_csa_pass": (_i, [_vp, _i, _vp, _vp]),
     "sarx_csa_plan_mark_range": (_i, [_vp, _i, _i]),
+    "sarx_csa_plan_stamp_range": (_i, [_vp, _vp]),
     "sarx_csa_plan_set_look_slot": (_i, [_vp, _i, _vp]),
     "sarx_csa_plan_set_max_slot": (_i, [_vp, _vp]),
     "sarx_csa_plan_set_ati": (_i, [_vp, _vp, _vp, _f, _d, _vp, _vp, _vp, _i]),

@@ -246,6 +246,8 @@ class TwoChannelBatch:
         # Results do not depend on it (same kernels, separate buffers).
         if lanes is None:                   # frames of 4096^2 and more gain 3-8 %; small frames are launch-bound and lose to the lane switches
             lanes = 2 if n >= 4096 else 1
+        if world > 1 and not rccl:          # host transport: every round ends in a blocking download that waits for every lane - one frame in flight
+            lanes = 1
         self.lanes = max(1, min(int(lanes), 4))
         self.range_cus = 192                # of 256: sarx_set_range_cus while frames are in flight (only the persistent 16384-sample launch looks at it)
         self._lane_state = []
@@ -386,6 +388,20 @@ class TwoChannelBatch:
         self.prepare()
         if self.lanes > 1:
             ctx.set_range_cus(self.range_cus)                       # persistent range launches leave CUs to the other lane's azimuth tiles
+        try:
+            self._run_rounds()
+        finally:                                                    # the CU share and the lane are context state: never left behind by an exception
+            self.use_lane(0)
+            if self.lanes > 1:
+                ctx.set_range_cus(0)
+        if self.lanes > 1:
+            ctx.lanes_join()                                        # whatever follows on any lane sees every frame finished
+        if self.rccl and self.world > 1:
+            ctx.comm_sync()
+
+    def _run_rounds(self):
+        from ._ffi import check
+        ctx = self.ctx
         for i in range(self.n_rounds):
             self.use_lane(i)
             mine_ptr = self._slot_ptr(i, self.rank)
@@ -406,12 +422,6 @@ class TwoChannelBatch:
                 check(ctx.lib.sarx_memcpy_d2h(ctx.h, slot.ctypes.data, mine_ptr, self.slot_bytes), ctx.h)
                 block = np.ascontiguousarray(self.host_comm.all_gather(slot))
                 check(ctx.lib.sarx_memcpy_h2d(ctx.h, self._slot_ptr(i, 0), block.ctypes.data, block.nbytes), ctx.h)
-        self.use_lane(0)
-        if self.lanes > 1:
-            ctx.set_range_cus(0)
-            ctx.lanes_join()                                        # whatever follows on any lane sees every frame finished
-        if self.rccl and self.world > 1:
-            ctx.comm_sync()
 
     def global_max(self):
         """g_max of the whole stack (sar_batch_sim.py:337-338: max over all frames of max|frame|; 0 -> 1.0) without reading the

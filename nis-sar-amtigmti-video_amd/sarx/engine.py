@@ -452,6 +452,11 @@ class CsaPlan:
         """focus_dev records ctx events around its range pass(es) (roofline kernel timing)."""
         check(self.ctx.lib.sarx_csa_plan_mark_range(self.h, int(slot_start), int(slot_stop)), self.ctx.h)
 
+    def stamp_range(self, pair_ptr=None):
+        """focus_dev's fused range launch leaves {first workgroup start, last workgroup end} (100 MHz ticks) in the two uint64 at
+        the device address pair_ptr, which the caller has initialised to {2**64 - 1, 0}; None switches it off (sarx_csa_plan_stamp_range)."""
+        check(self.ctx.lib.sarx_csa_plan_stamp_range(self.h, pair_ptr if pair_ptr else None), self.ctx.h)
+
     def set_look_slot(self, looks, slot_ptr):
         """Every later focus_dev also writes the looks x looks multilook of |image|^2 to the device address slot_ptr
         (None / 0 switches it off): the VideoSAR stack slot without reading the image again."""
@@ -504,7 +509,13 @@ class FocusLanes:
         if self.lanes > 1:
             self.ctx.select_lane(self.lane_ids[lane])
             self.ctx.set_range_cus(self.range_cus)     # the persistent range launch leaves CUs to the other lane's azimuth tiles
-        self.plans[lane].focus_dev(d_phist, d_image)
+        try:
+            self.plans[lane].focus_dev(d_phist, d_image)
+        except BaseException:                          # the CU share and the lane are context state: not left behind by a failed enqueue
+            if self.lanes > 1:
+                self.ctx.select_lane(0)
+                self.ctx.set_range_cus(0)
+            raise
         return lane
 
     def finish(self):

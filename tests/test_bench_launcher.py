@@ -76,3 +76,37 @@ def test_driver_style_launch_of_eight_ranks_sets_the_ipc_mode_itself():
     line = json.loads(lines[0])
     assert line["dry_run"] and line["n_gpus"] == 8 and sorted(x["rank"] for x in line["ranks"]) == list(range(8))
     assert all(x["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for x in line["ranks"])
+
+
+def _eight(env_extra, extra_args=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "8", "--dry-run", *extra_args]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_first_scaling_run_cannot_fall_back_to_host_memory_silently():
+    """Eight ranks, eight devices (the driver's scaling run), RCCL bring-up failing on ONE rank: every rank exits non-zero together
+    and no JSON line is printed - the first 8-GPU number cannot be a gloo-through-host-memory figure that only a flag marks.  The
+    same failure with ranks outnumbering the GPUs (a rehearsal on one card), or with --allow-host-transport, falls back and says so;
+    --require-rccl makes the rehearsal strict too.  (agree_on_rccl and the policy are bench.py's own; the communicator is a stand-in.)"""
+    r = _eight({"SARX_BENCH_REHEARSE_RCCL_FAIL": "5", "SARX_BENCH_REHEARSE_DEVICES": "8"})
+    assert r.returncode != 0, r.stdout
+    assert "exiting 3 on every rank" in r.stderr and r.stderr.count("exiting 3 on every rank") == 8
+    assert not [x for x in r.stdout.splitlines() if x.startswith("{")]
+    r = _eight({"SARX_BENCH_REHEARSE_RCCL_FAIL": "-1", "SARX_BENCH_REHEARSE_DEVICES": "8"})       # the unique id itself fails on rank 0
+    assert r.returncode != 0 and r.stderr.count("exiting 3 on every rank") == 8
+    r = _eight({"SARX_BENCH_REHEARSE_RCCL_FAIL": "5", "SARX_BENCH_REHEARSE_DEVICES": "1"})        # eight ranks on one card: may fall back
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][0])
+    assert line["rccl_rehearsal"] == {"rccl_up": False, "required": False, "devices": 1}
+    r = _eight({"SARX_BENCH_REHEARSE_RCCL_FAIL": "5", "SARX_BENCH_REHEARSE_DEVICES": "1"}, ["--require-rccl"])
+    assert r.returncode != 0
+    r = _eight({"SARX_BENCH_REHEARSE_RCCL_FAIL": "5", "SARX_BENCH_REHEARSE_DEVICES": "8"}, ["--allow-host-transport"])
+    assert r.returncode == 0
+    r = _eight({"SARX_BENCH_REHEARSE_RCCL_FAIL": "", "SARX_BENCH_REHEARSE_DEVICES": "8"})          # nothing fails: RCCL up, required, fine
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][0])
+    assert line["rccl_rehearsal"] == {"rccl_up": True, "required": True, "devices": 8}
