@@ -85,7 +85,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
     rf = d.get("roofline", {})
     print(f.split("/")[-1], round(d["ms_per_step"], 3), "ms", round(d["value"], 1), d["unit"], "| roofline", rf.get("bound"), round(rf.get("frac", 0), 3),
           "alone", round(d.get("roofline_kernel_alone", {}).get("frac", 0), 3), "| phi2", round(d.get("roofline_rg_fft_phi2_pass", {}).get("frac", 0), 3),
-          "|", {k: round(v["value"], 1) for k, v in d.items() if isinstance(v, dict) and k.startswith(("batch64", "config"))},
+          "|", {k: round(v["value"], 1) for k, v in d.items() if isinstance(v, dict) and "value" in v and k.startswith(("batch64", "config"))},
           "| parity", d.get("parity"), "| cpu", (d.get("cpu_baseline") or {}).get("value"))
 PY
 }
