@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 205   /* 205: sarx_csa_plan_stamp_range (execution span of the fused range launch from in-kernel clock stamps); 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
+#define SARX_VERSION 205   /* 205: sarx_csa_plan_stamp_range (execution span of the fused range launch from in-kernel clock stamps), overlapped host transfers (sarx_memcpy_h2d_unordered, sarx_memcpy_d2h_begin / _end, sarx_csa_focus_host_begin / _end); 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -102,6 +102,17 @@ int sarx_host_alloc(sarx_ctx* ctx, size_t bytes, void** out_hptr);
 int sarx_host_free(sarx_ctx* ctx, void* hptr);
 int sarx_memcpy_h2d(sarx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int sarx_memcpy_d2h(sarx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Overlapped host transfers: PCIe is full duplex and both copies can run beside a focus, so a frame loop that calls
+ * sar_focus_csa on host arrays (sar_batch_sim.py:303-331; the two back-to-back channel calls of sar_ati_dcpa_sim_csa.py:410-411) need
+ * not pay upload + focus + download one after the other.
+ * sarx_memcpy_h2d_unordered: like sarx_memcpy_h2d (blocking for the caller, staged through pinned chunks by the copy threads), but
+ *   it does NOT wait for work already enqueued on the lanes: the caller guarantees that nothing enqueued reads or writes dst_dev.
+ * sarx_memcpy_d2h_begin: asynchronous download into PAGE-LOCKED host memory (sarx_host_alloc; SARX_ERR_INVALID for pageable memory)
+ *   on the ctx's download stream, ordered after everything enqueued so far on the current lane; *out_slot identifies it (eight may be
+ *   in flight).  sarx_memcpy_d2h_end(slot) blocks until that copy has landed.  sarx_sync waits for all of them too. */
+int sarx_memcpy_h2d_unordered(sarx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int sarx_memcpy_d2h_begin(sarx_ctx* ctx, void* dst_host_pinned, const void* src_dev, size_t bytes, int* out_slot);
+int sarx_memcpy_d2h_end(sarx_ctx* ctx, int slot);
 int sarx_memcpy_d2d(sarx_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 /* strided copies (rows of `width` bytes, pitches in bytes), blocking: sample columns / blocks of a device image */
 int sarx_memcpy2d_d2h(sarx_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
@@ -151,6 +162,15 @@ int sarx_csa_focus_host(sarx_plan* plan, const void* phist_host, void* image_hos
 /* the same with phist as complex128 (the dtype the reference's arrays have, sar_ati_dcpa_sim_csa.py:135): rounded to complex64
  * while it is staged for the transfer, by the copy threads; the image comes back as complex64 */
 int sarx_csa_focus_host_c128(sarx_plan* plan, const void* phist_c128_host, void* image_host);
+/* sarx_csa_focus_host as a two-deep pipeline.  _begin uploads the frame (blocking for the caller, but without waiting for the frame
+ * that is still focusing or downloading), enqueues its focus and - when image_host is page-locked (sarx_host_alloc) - its download on
+ * the download stream, and returns a ticket; _end(ticket) blocks until that frame's image is complete in image_host (a pageable
+ * image_host is downloaded there, staged and blocking: no overlap for that half).  Called as begin(i+1), end(i), begin(i+2), ... frame
+ * i+1 uploads while frame i focuses and downloads: 2 GiB each way at 16384^2 in ~41-46 ms per frame instead of 82-88.  Both host
+ * buffers must stay valid and untouched until _end; at most two frames per plan are in flight (a third _begin returns
+ * SARX_ERR_INVALID); results are bit-identical to sarx_csa_focus_host.  The plan owns two more image pairs on the device for it. */
+int sarx_csa_focus_host_begin(sarx_plan* plan, const void* phist_host, void* image_host, int* out_ticket);
+int sarx_csa_focus_host_end(sarx_plan* plan, int ticket);
 /* device in / device out, asynchronous on the ctx stream.  d_phist is not modified.
  * d_image must not alias d_phist. */
 int sarx_csa_focus_dev(sarx_plan* plan, const void* d_phist, void* d_image);

@@ -101,7 +101,8 @@ bool range_v2_supported(int n_rg, int mode);
 hipError_t launch_range_pass_v2(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st);
 // range_fused_wl.hip: fused FFT.Phi2.IFFT.Phi3 at 16384 with wave-private sub-transforms
 bool range_fused_wl_supported(int n_rg);
-hipError_t launch_range_fused_wl(const RangeArgs& a, int cus, hipStream_t st);
+// alone: the launch has the chip to itself (no frames in flight on other lanes): next-line touch prefetch on
+hipError_t launch_range_fused_wl(const RangeArgs& a, int cus, hipStream_t st, bool alone = false);
 // range_mixed.hip: direct mixed-radix lines (13200 = 24 * 22 * 25, the reference's native range extent), all modes
 bool range_mixed_supported(int n_rg);
 hipError_t launch_range_mixed(int n_rg, int mode, const RangeArgs& a, int cus, hipStream_t st);

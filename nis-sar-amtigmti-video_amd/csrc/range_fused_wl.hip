@@ -79,8 +79,17 @@ template <bool INV> __device__ __forceinline__ void sub1024_r32(cf* v, int i, cf
 }
 }  // namespace wl
 
-__global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArgs a) {
+// PF = 1 (round 5): every thread touches two 128-byte lines of the NEXT line of its workgroup once this line's own loads have landed
+// (one dword each into a register nobody reads: the data is wanted in L2 / the Infinity Cache, where the loads at the top of the next
+// iteration then find it).  No register prefetch fits this kernel; this costs ten VGPRs.  Alone on the GPU and in place the launch runs
+// 1.040 against 1.089 ms (0.516 against 0.493 of the HBM peak, profiles/r05_f_wl_touch_prefetch.log); with two frames in flight the
+// extra requests compete with the other lane's azimuth tiles and the frame gets 1 % SLOWER, so the launcher uses it only when the
+// launch has the chip to itself (no CU share set).  Touching right behind the line's own loads, and nontemporal stores with or without
+// the touch, measured worse or equal (same log).
+template <int PF>
+__device__ __forceinline__ void range_fused_wl_body(const RangeArgs& a) {
     using namespace wl;
+    constexpr bool TOUCH = (PF == 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);
     if (a.stamp && threadIdx.x == 0) atomicMin(a.stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -105,6 +114,7 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
 #pragma unroll
         for (int q = 2; q < 16; ++q) cw[b][q] = cmul(cw[b][q / 2], cw[b][q - q / 2]);
     }
+    unsigned pf0 = 0, pf1 = 0;                        // destinations of the touch loads: reserved until the loads have landed
     for (int line = blockIdx.x; line < a.n_az; line += gridDim.x) {
         const int row = range_row(a, line);
         int t = threadIdx.x;
@@ -120,6 +130,14 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
             v[r] = make_float2(q4.x, q4.y);
             v[16 + r] = make_float2(q4.z, q4.w);
         }
+        auto touch_next = [&] {
+            const int nl = line + (int)gridDim.x;
+            if (nl < a.n_az) {                        // 1024 lines of 128 bytes per 16384-sample row: two per thread
+                const cf* np = a.in + (size_t)range_row(a, nl) * N + 16 * t;
+                asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                             : "=&v"(pf0), "=&v"(pf1) : "v"(np), "v"(np + 16 * THREADS) : "memory");
+            }
+        };
         // the row's phase constants through the scalar cache, behind the line's own loads (their latency covers it): as vector
         // loads next to their use their latency was exposed twice per line
         const double2 c2 = sload_double2(a.c2 + row), c3 = sload_double2(a.c3 + row);
@@ -132,7 +150,13 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
         }
         cf* img = lds + (2 * w + (l >> 5)) * ROWSTR;  // the half wave's private image
         const int li = l & 31;
+        if constexpr (TOUCH) {
+            // vmcnt retires in order: this line's loads are younger than the previous iteration's touch loads, so a value computed from
+            // v[] (the butterflies above waited for it) proves pf0 / pf1 have been written: their registers may be reused from here on
+            asm volatile("" :: "v"(pf0), "v"(pf1), "v"(v[0].x), "v"(v[31].y));
+        }
         cross_fwd32(v, t, w, l, lds, line != (int)blockIdx.x);
+        if constexpr (TOUCH) touch_next();
         sub1024_r32<false>(v, li, img, wp);
         // Phi_2: v[r] is bin k = (2w+h) + 16 i + 512 r; r >= 16 are the negative frequencies
         {
@@ -170,23 +194,31 @@ __global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArg
             }
         }
     }
+    if constexpr (TOUCH) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the last touch loads have landed before their registers die
+        asm volatile("" :: "v"(pf0), "v"(pf1));
+    }
     if (a.stamp && threadIdx.x == 0) {                // after this wave's last stores have been acknowledged
         __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
         atomicMax(a.stamp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
+__global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_kernel(RangeArgs a) { range_fused_wl_body<0>(a); }
+__global__ __launch_bounds__(wl::THREADS, 2) void range_fused_wl_touch_kernel(RangeArgs a) { range_fused_wl_body<1>(a); }
 
 bool range_fused_wl_supported(int n_rg) { return n_rg == wl::N; }
 
 // cus: compute units of the device the stream belongs to (from the ctx).  The 136 KiB dynamic-LDS opt-in is a
 // per-device attribute of the function, so it is set on every launch like the other launchers do (a process may own
 // contexts on several GPUs; a once-per-process flag would leave the second device without it).
-hipError_t launch_range_fused_wl(const RangeArgs& a, int cus, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_fused_wl_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl::LDS_BYTES);
+hipError_t launch_range_fused_wl(const RangeArgs& a, int cus, hipStream_t st, bool alone) {
+    static const int pf = [] { const char* e = getenv("SARX_WL_PREFETCH"); return e ? atoi(e) : -1; }();      // 0 / 1 force it off / on (A/B)
+    const bool touch = pf < 0 ? (alone && a.in == a.out) : pf == 1;
+    auto k = touch ? range_fused_wl_touch_kernel : range_fused_wl_kernel;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl::LDS_BYTES);
     if (e != hipSuccess) return e;
     const int grid = persistent_grid(1, cus, a.n_az);   // one resident workgroup per CU, persistent over lines
-    hipLaunchKernelGGL(range_fused_wl_kernel, dim3(grid), dim3(wl::THREADS), wl::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(wl::THREADS), wl::LDS_BYTES, st, a);
     return hipGetLastError();
 }
 

@@ -119,6 +119,13 @@ struct sarx_ctx {
     char* pin[COPY_THREADS] = {};
     hipStream_t copy_stream[COPY_THREADS] = {};
     std::mutex copy_mu;                // the pinned chunks and copy streams are per-ctx state: one staged copy at a time
+    // overlapped host transfers (sarx_memcpy_h2d_unordered, sarx_memcpy_d2h_begin / _end): downloads run on their own stream behind an
+    // event of the producing lane, uploads into free buffers do not wait for enqueued GPU work - PCIe is full duplex
+    static constexpr int DL_SLOTS = 8;
+    hipStream_t dl_stream = nullptr, up_stream = nullptr;
+    hipEvent_t dl_ready[DL_SLOTS] = {};    // recorded on the producing lane
+    hipEvent_t dl_done[DL_SLOTS] = {};     // recorded on dl_stream behind the copy
+    bool dl_busy[DL_SLOTS] = {};
     ncclComm_t comm = nullptr;
     int n_ranks = 0, rank = 0;
     int range_cus = 0;                 // > 0: persistent range launches size their grid for this many CUs (sarx_set_range_cus; frames in flight)
@@ -148,6 +155,12 @@ struct sarx_plan {
     float2* buf_b = nullptr;           // scratch image
     float2* buf_a = nullptr;           // second scratch (RG_MAJOR only)
     float2 *h_in = nullptr, *h_out = nullptr;   // device staging for the *_host entry point
+    // sarx_csa_focus_host_begin / _end: PIPE frames in flight between upload, focus and download
+    static constexpr int PIPE = 2;
+    float2 *pipe_in[PIPE] = {}, *pipe_out[PIPE] = {};
+    int pipe_dl[PIPE] = {-1, -1};           // ctx download slot of the frame in pipeline slot i, -1 = free
+    void* pipe_host[PIPE] = {};             // pageable destination of slot i (downloaded by _end), NULL when the DMA already targets it
+    int pipe_next = 0;
     uint64_t bytes = 0;
     int mark_start = -1, mark_stop = -1;   // ctx event slots recorded around the range pass(es)
     unsigned long long* stamp = nullptr;   // sarx_csa_plan_stamp_range: {min start, max end} of the fused range launch (s_memrealtime ticks)
@@ -182,23 +195,30 @@ static hipError_t sync_all_lanes(sarx_ctx* c) {
 // 51-54 GB/s both ways.  Blocking; ordered after everything on the ctx stream.  Small copies take the plain path.
 // narrow: (host -> device only) the host buffer holds complex128 and is rounded to complex64 on the way into the pinned chunk
 // (the reference's arrays are complex128; a NumPy astype of 2^28 elements costs more than the whole transfer)
-static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, bool narrow = false) {
-    hipError_t e = sync_all_lanes(c);
+// ordered = false (uploads into a buffer no enqueued work touches, downloads of data already complete): the copy does not wait for
+// the lanes and runs on streams of its own, so it overlaps whatever the GPU is doing
+static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, bool narrow = false, bool ordered = true) {
+    hipError_t e = ordered ? sync_all_lanes(c) : hipSuccess;
     if (e != hipSuccess) return e;
+    hipStream_t direct = c->stream;
+    if (!ordered) {
+        if (!c->up_stream && (e = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        direct = c->up_stream;
+    }
     if (!narrow && bytes >= 4 * sarx_ctx::COPY_CHUNK) {
         // a buffer from sarx_host_alloc (page-locked, already faulted in) needs no staging: one DMA at the PCIe rate, no host memcpy,
         // no first touch.  A pointer the runtime does not know is ordinary pageable memory (the query fails for it: clear that error).
         hipPointerAttribute_t at{};
         const void* host = to_device ? src : dst;
         if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost) {
-            e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, c->stream);
-            return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+            e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, direct);
+            return e != hipSuccess ? e : hipStreamSynchronize(direct);
         }
         (void)hipGetLastError();
     }
     if (bytes < 4 * sarx_ctx::COPY_CHUNK && !narrow) {
-        e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, c->stream);
-        return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+        e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, direct);
+        return e != hipSuccess ? e : hipStreamSynchronize(direct);
     }
     constexpr int T = sarx_ctx::COPY_THREADS;
     constexpr size_t CH = sarx_ctx::COPY_CHUNK;
@@ -335,6 +355,12 @@ int sarx_destroy(sarx_ctx* c) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
         if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
     }
+    for (int i = 0; i < sarx_ctx::DL_SLOTS; ++i) {
+        if (c->dl_ready[i]) hipEventDestroy(c->dl_ready[i]);
+        if (c->dl_done[i]) hipEventDestroy(c->dl_done[i]);
+    }
+    if (c->dl_stream) hipStreamDestroy(c->dl_stream);
+    if (c->up_stream) hipStreamDestroy(c->up_stream);
     for (int k = 0; k < sarx_ctx::LANES; ++k) {
         if (c->lane_ev[k]) hipEventDestroy(c->lane_ev[k]);
         if (k > 0 && c->lane[k]) hipStreamDestroy(c->lane[k]);
@@ -392,6 +418,46 @@ int sarx_memcpy_d2h(sarx_ctx* c, void* d, const void* s, size_t n) {
 int sarx_memcpy_d2d(sarx_ctx* c, void* d, const void* s, size_t n) {
     NEED_CTX(c);
     HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream));
+    return SARX_OK;
+}
+int sarx_memcpy_h2d_unordered(sarx_ctx* c, void* d, const void* s, size_t n) {
+    NEED_CTX(c);
+    if (!d || !s) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    HIPCHK(c, staged_copy(c, d, s, n, true, false, /*ordered=*/false));
+    return SARX_OK;
+}
+static bool is_page_locked(const void* p) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return true;
+    (void)hipGetLastError();
+    return false;
+}
+int sarx_memcpy_d2h_begin(sarx_ctx* c, void* h, const void* d, size_t n, int* out_slot) {
+    NEED_CTX(c);
+    if (!h || !d || !out_slot) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    *out_slot = -1;
+    if (!is_page_locked(h))
+        return fail(c, SARX_ERR_INVALID, "sarx_memcpy_d2h_begin needs a page-locked destination (sarx_host_alloc): a pageable one cannot be "
+                                         "written by an asynchronous DMA (use sarx_memcpy_d2h)");
+    int slot = -1;
+    for (int i = 0; i < sarx_ctx::DL_SLOTS; ++i) if (!c->dl_busy[i]) { slot = i; break; }
+    if (slot < 0) return fail(c, SARX_ERR_INVALID, "all %d download slots are in flight: call sarx_memcpy_d2h_end first", sarx_ctx::DL_SLOTS);
+    if (!c->dl_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+    if (!c->dl_ready[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->dl_ready[slot], hipEventDisableTiming));
+    if (!c->dl_done[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->dl_done[slot], hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->dl_ready[slot], c->stream));              // everything enqueued on the current lane so far
+    HIPCHK(c, hipStreamWaitEvent(c->dl_stream, c->dl_ready[slot], 0));
+    if (n) HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->dl_stream));
+    HIPCHK(c, hipEventRecord(c->dl_done[slot], c->dl_stream));
+    c->dl_busy[slot] = true;
+    *out_slot = slot;
+    return SARX_OK;
+}
+int sarx_memcpy_d2h_end(sarx_ctx* c, int slot) {
+    NEED_CTX(c);
+    if (slot < 0 || slot >= sarx_ctx::DL_SLOTS || !c->dl_busy[slot]) return fail(c, SARX_ERR_INVALID, "download slot %d is not in flight", slot);
+    c->dl_busy[slot] = false;                                            // released whatever the wait returns
+    HIPCHK(c, hipEventSynchronize(c->dl_done[slot]));
     return SARX_OK;
 }
 int sarx_memcpy2d_d2h(sarx_ctx* c, void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height) {
@@ -473,6 +539,7 @@ int sarx_sync(sarx_ctx* c) {
     NEED_CTX(c);
     HIPCHK(c, sync_all_lanes(c));
     HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    if (c->dl_stream) HIPCHK(c, hipStreamSynchronize(c->dl_stream));
     return SARX_OK;
 }
 int sarx_event_record(sarx_ctx* c, int slot) {
@@ -582,6 +649,8 @@ int sarx_csa_plan_destroy(sarx_plan* p) {
     hipFree(p->c1); hipFree(p->c2); hipFree(p->c3);
     hipFree(p->ati_part);
     hipFree(p->buf_a); hipFree(p->buf_b); hipFree(p->h_in); hipFree(p->h_out); hipFree(p->look_part);
+    if (p->ctx->dl_stream) hipStreamSynchronize(p->ctx->dl_stream);
+    for (int i = 0; i < sarx_plan::PIPE; ++i) { hipFree(p->pipe_in[i]); hipFree(p->pipe_out[i]); }
     delete p;
     return SARX_OK;
 }
@@ -721,7 +790,8 @@ static hipError_t run_range(const sarx_plan* p, int mode, const RangeArgs& a) {
                     (c->range_impl == 2 || (c->range_impl == 0 && p->n_rg >= 16384 && mode != RG_FUSED));
     // impl 3 (default for the fused launch at 16384): wave-private sub-transforms
     if (mode == RG_FUSED && range_fused_wl_supported(p->n_rg) && (c->range_impl == 3 || c->range_impl == 0))
-        return launch_range_fused_wl(a, (c->range_cus > 0 && c->range_cus < c->cus) ? c->range_cus : c->cus, c->stream);
+        return launch_range_fused_wl(a, (c->range_cus > 0 && c->range_cus < c->cus) ? c->range_cus : c->cus, c->stream,
+                                     /*alone=*/!(c->range_cus > 0 && c->range_cus < c->cus));
     return v2 ? launch_range_pass_v2(p->n_rg, mode, a, c->cus, c->stream) : launch_range_pass(p->n_rg, mode, a, c->stream);
 }
 
@@ -971,6 +1041,50 @@ int sarx_csa_focus_host(sarx_plan* p, const void* phist_host, void* image_host) 
     if (rc != SARX_OK) return rc;
     HIPCHK(c, staged_copy(c, image_host, p->h_out, img, false));
     return SARX_OK;
+}
+
+// The host-array call as a pipeline (the loop of sar_batch_sim.py:303-331, the two back-to-back calls of sar_ati_dcpa_sim_csa.py:410-411):
+// _begin uploads this frame while the previous frame focuses and downloads; _end waits for a frame's image.
+int sarx_csa_focus_host_begin(sarx_plan* p, const void* phist_host, void* image_host, int* out_ticket) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (!phist_host || !image_host || !out_ticket) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    *out_ticket = -1;
+    const int s = p->pipe_next;
+    if (p->pipe_dl[s] != -1) return fail(c, SARX_ERR_INVALID, "%d frames are in flight on this plan: call sarx_csa_focus_host_end first", sarx_plan::PIPE);
+    const size_t img = (size_t)p->n_az * p->n_rg * sizeof(float2);
+    for (float2** b : {&p->pipe_in[s], &p->pipe_out[s]})
+        if (!*b) { hipError_t e = hipMalloc(b, img); if (e != hipSuccess) return fail(c, SARX_ERR_NOMEM, "hipMalloc pipeline buffer: %s", hipGetErrorString(e)); }
+    // slot s last held frame i - PIPE, whose _end has returned: nothing enqueued touches these two buffers, the upload need not wait
+    // for the frame that is focusing or downloading right now
+    HIPCHK(c, staged_copy(c, p->pipe_in[s], phist_host, img, true, false, /*ordered=*/false));
+    int rc = sarx_csa_focus_dev(p, p->pipe_in[s], p->pipe_out[s]);
+    if (rc != SARX_OK) return rc;
+    if (is_page_locked(image_host)) {
+        int slot = -1;
+        if ((rc = sarx_memcpy_d2h_begin(c, image_host, p->pipe_out[s], img, &slot)) != SARX_OK) return rc;
+        p->pipe_dl[s] = slot; p->pipe_host[s] = nullptr;
+    } else {                       // a pageable result cannot be the target of an asynchronous DMA: _end downloads it (staged, blocking)
+        p->pipe_dl[s] = sarx_ctx::DL_SLOTS; p->pipe_host[s] = image_host;
+    }
+    p->pipe_next = (s + 1) % sarx_plan::PIPE;
+    *out_ticket = s;
+    return SARX_OK;
+}
+int sarx_csa_focus_host_end(sarx_plan* p, int ticket) {
+    if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
+    sarx_ctx* c = p->ctx;
+    hipSetDevice(c->device);
+    if (ticket < 0 || ticket >= sarx_plan::PIPE || p->pipe_dl[ticket] == -1) return fail(c, SARX_ERR_INVALID, "ticket %d is not in flight", ticket);
+    const int slot = p->pipe_dl[ticket];
+    p->pipe_dl[ticket] = -1;
+    if (slot == sarx_ctx::DL_SLOTS) {
+        const size_t img = (size_t)p->n_az * p->n_rg * sizeof(float2);
+        HIPCHK(c, staged_copy(c, p->pipe_host[ticket], p->pipe_out[ticket], img, false));      // ordered: waits for the focus
+        return SARX_OK;
+    }
+    return sarx_memcpy_d2h_end(c, slot);
 }
 
 // ---- Range-Doppler focus ---------------------------------------------------------------

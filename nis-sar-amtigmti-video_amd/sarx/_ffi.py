@@ -64,6 +64,9 @@ SIGNATURES = {
     "sarx_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_memcpy_h2d_unordered": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_memcpy_d2h_begin": (_i, [_vp, _vp, _vp, _sz, _P(_i)]),
+    "sarx_memcpy_d2h_end": (_i, [_vp, _i]),
     "sarx_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "sarx_memcpy2d_h2d": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "sarx_memset": (_i, [_vp, _vp, _i, _sz]),
@@ -79,6 +82,8 @@ SIGNATURES = {
     "sarx_csa_plan_destroy": (_i, [_vp]),
     "sarx_csa_axes": (_i, [_vp, _vp, _vp]),
     "sarx_csa_focus_host": (_i, [_vp, _vp, _vp]),
+    "sarx_csa_focus_host_begin": (_i, [_vp, _vp, _vp, _P(_i)]),
+    "sarx_csa_focus_host_end": (_i, [_vp, _i]),
     "sarx_csa_focus_host_c128": (_i, [_vp, _vp, _vp]),
     "sarx_csa_focus_dev": (_i, [_vp, _vp, _vp]),
     "sarx_csa_pass": (_i, [_vp, _i, _vp, _vp]),

@@ -42,12 +42,49 @@ class DeviceBuffer:
         check(self.ctx.lib.sarx_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes), self.ctx.h)
         return self
 
+    def upload_unordered(self, arr):
+        """upload() that does not wait for GPU work already enqueued: the caller guarantees nothing enqueued touches this buffer, and
+        the copy then overlaps whatever the GPU is doing (sarx_memcpy_h2d_unordered)."""
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > self.nbytes:
+            raise ValueError("upload larger than buffer")
+        check(self.ctx.lib.sarx_memcpy_h2d_unordered(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes), self.ctx.h)
+        return self
+
+    def download_begin(self, dtype, shape):
+        """Asynchronous download, ordered after everything enqueued so far on the current lane: returns a PendingDownload whose
+        result() waits for the copy and returns the array (page-locked, from the context's pool: reserve it with
+        Context.reserve_pinned so the first calls of a loop do not pay hipHostMalloc).  Overlaps later uploads and kernels."""
+        out = self.ctx.pinned_empty(shape, dtype, force=True)
+        if out.nbytes > self.nbytes:
+            raise ValueError("download larger than buffer")
+        return PendingDownload(self.ctx, out, self.ptr)
+
     def download(self, dtype, shape):
         out = self.ctx.pinned_empty(shape, dtype)            # large results: page-locked pool (one DMA, no first touch)
         if out.nbytes > self.nbytes:
             raise ValueError("download larger than buffer")
         check(self.ctx.lib.sarx_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes), self.ctx.h)
         return out
+
+
+class PendingDownload:
+    """A device-to-host copy in flight on the context's download stream (sarx_memcpy_d2h_begin); result() waits for it."""
+
+    def __init__(self, ctx, out, src_ptr):
+        self.ctx, self.out, self.slot = ctx, out, None
+        if ctx.is_pinned(out):
+            slot = C.c_int(-1)
+            check(ctx.lib.sarx_memcpy_d2h_begin(ctx.h, out.ctypes.data, src_ptr, out.nbytes, C.byref(slot)), ctx.h)
+            self.slot = slot.value
+        else:                                   # no page-locked block to be had (pool budget): the ordinary blocking copy
+            check(ctx.lib.sarx_memcpy_d2h(ctx.h, out.ctypes.data, src_ptr, out.nbytes), ctx.h)
+
+    def result(self):
+        if self.slot is not None:
+            slot, self.slot = self.slot, None
+            check(self.ctx.lib.sarx_memcpy_d2h_end(self.ctx.h, slot), self.ctx.h)
+        return self.out
 
 
 def download_block(ctx, ptr, ld_elems, row0, n_rows, col0, n_cols, dtype=np.complex64):
@@ -182,7 +219,34 @@ class Context:
         return self.scratch(tag, arr.nbytes).upload(arr)
 
     # -- pooled page-locked result arrays --
-    def pinned_empty(self, shape, dtype):
+    def last_error(self):
+        """Text of the last error a call on this context set (sarx_last_error)."""
+        return self.lib.sarx_last_error(self.h).decode(errors="replace")
+
+    def reserve_pinned(self, shape, dtype, count=1):
+        """Page-lock `count` result blocks of this shape now, so that a frame loop never meets hipHostMalloc (0.15 s per GiB) in the
+        middle: the blocks wait in the pool and pinned_empty hands them out from the first request on.  Returns how many blocks of
+        that size the pool holds free afterwards (fewer than asked for if the pool budget SARX_PINNED_POOL_GIB is exhausted)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        with self._pinned_lock:
+            free = self._pinned_free.setdefault(nbytes, [])
+            while len(free) < int(count) and self._pinned_total + nbytes <= self._pinned_cap and self.h is not None:
+                out = C.c_void_p()
+                if self.lib.sarx_host_alloc(self.h, nbytes, C.byref(out)) != 0 or not out.value:
+                    break
+                free.append(out.value)
+                self._pinned_total += nbytes
+            self._pinned_seen[nbytes] = max(self._pinned_seen.get(nbytes, 0), self.PINNED_FROM_REQUEST)
+            return len(free)
+
+    def is_pinned(self, arr):
+        """True if the array's memory is a block of this context's page-locked pool."""
+        base = arr
+        while isinstance(base, np.ndarray) and base.base is not None:
+            base = base.base
+        return isinstance(base, _PinnedBlock)
+
+    def pinned_empty(self, shape, dtype, force=False):
         """np.empty(shape, dtype) on page-locked memory from a per-context pool (results of the *_host entry points): the
         download is one DMA at the PCIe rate and a repeated call of the same size pays neither hipHostMalloc nor the first touch
         of fresh pages.  The array is the caller's like any NumPy result; its block returns to the pool when the array and all
@@ -198,7 +262,7 @@ class Context:
             free = self._pinned_free.get(nbytes)
             ptr = free.pop() if free else None
             if ptr is None:
-                if seen < self.PINNED_FROM_REQUEST or self._pinned_total + nbytes > self._pinned_cap:
+                if (seen < self.PINNED_FROM_REQUEST and not force) or self._pinned_total + nbytes > self._pinned_cap:
                     return np.empty(shape, dtype)
                 out = C.c_void_p()
                 if self.lib.sarx_host_alloc(self.h, nbytes, C.byref(out)) != 0 or not out.value:
@@ -447,6 +511,27 @@ class CsaPlan:
         fn = self.ctx.lib.sarx_csa_focus_host_c128 if wide else self.ctx.lib.sarx_csa_focus_host
         check(fn(self.h, a.ctypes.data, out.ctypes.data), self.ctx.h)
         return out
+
+    def focus_host_begin(self, phist, out=None):
+        """First half of focus_host as a two-deep pipeline (sarx_csa_focus_host_begin): uploads this frame without waiting for the one
+        that is still focusing / downloading, enqueues its focus and the download of its image into `out` (default: a page-locked
+        array from the context's pool) and returns (ticket, out).  focus_host_end(ticket) waits for the image.  `phist` must stay
+        untouched until then; at most two frames per plan are in flight."""
+        a = np.ascontiguousarray(phist, dtype=np.complex64)
+        if a.shape != (self.n_az, self.n_rg):
+            raise ValueError(f"phist shape {a.shape} != plan ({self.n_az}, {self.n_rg})")
+        shape = (self.n_rg, self.n_az) if self.rg_major else (self.n_az, self.n_rg)
+        if out is None:
+            out = self.ctx.pinned_empty(shape, np.complex64, force=True)
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.complex64 and out.shape == shape and out.flags.c_contiguous
+                  and out.flags.writeable):
+            raise ValueError(f"out must be a writeable C-contiguous complex64 array of shape {shape}")
+        ticket = C.c_int(-1)
+        check(self.ctx.lib.sarx_csa_focus_host_begin(self.h, a.ctypes.data, out.ctypes.data, C.byref(ticket)), self.ctx.h)
+        return (ticket.value, a), out           # the ticket keeps the (possibly converted) input alive until _end
+
+    def focus_host_end(self, ticket):
+        check(self.ctx.lib.sarx_csa_focus_host_end(self.h, int(ticket[0])), self.ctx.h)
 
     def mark_range(self, slot_start=-1, slot_stop=-1):
         """focus_dev records ctx events around its range pass(es) (roofline kernel timing)."""

@@ -83,6 +83,70 @@ def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     return (img if materialize_transpose else img.T), range_axis, cross_range_axis
 
 
+class FocusFuture:
+    """Result of sar_focus_csa_async: result() waits for the frame and returns what sar_focus_csa returns."""
+
+    def __init__(self, plan, ticket, img, transposed_view):
+        self._plan, self._ticket, self._img, self._view = plan, ticket, img, transposed_view
+        self._axes = None
+
+    def done(self):
+        return self._ticket is None
+
+    def result(self):
+        if self._ticket is not None:
+            ticket, self._ticket = self._ticket, None
+            self._plan.focus_host_end(ticket)
+        if self._axes is None:
+            self._axes = self._plan.axes()
+        return (self._img.T if self._view else self._img), self._axes[0], self._axes[1]
+
+
+def sar_focus_csa_async(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+                        platform_speed_mps, range_ref_m, t_start_fast, *, ctx=None, fuse_range=True,
+                        materialize_transpose=False, out=None):
+    """sar_focus_csa (sar_ati_dcpa_sim_csa.py:202-396) returning a FocusFuture at once: the frame's upload has happened, its focus
+    and its download are in flight.  Calling it for the next frame BEFORE result() of this one overlaps that frame's upload with
+    this frame's focus and download (PCIe is full duplex): the loop of sar_batch_sim.py:303-331 at ~41-46 ms per 16384^2 frame
+    instead of 82-88.  At most two futures per (size, radar) may be pending; `phist` must not be modified before result().
+    Same results, bit for bit, as sar_focus_csa."""
+    a = np.asarray(phist)
+    if a.ndim != 2:
+        raise ValueError("phist must be 2-D [N_pulses x N_samples]")
+    ctx = ctx or default_context()
+    n_az, n_rg = a.shape
+    flags = (_ffi.FUSE_RANGE if fuse_range else 0) | (_ffi.OUT_RG_MAJOR if materialize_transpose else 0)
+    args = (center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+            platform_speed_mps, range_ref_m, t_start_fast)
+    plan = _get_plan(ctx, n_az, n_rg, args, flags)
+    dst = None
+    if out is not None:
+        dst = out if materialize_transpose else out.T
+    ticket, img = plan.focus_host_begin(a, out=dst)
+    return FocusFuture(plan, ticket, img, not materialize_transpose)
+
+
+def focus_stream(frames, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+                 platform_speed_mps, range_ref_m, t_start_fast, *, ctx=None, reserve=3, **kw):
+    """Generator over an iterable of raw frames (host arrays of one shape): yields sar_focus_csa's tuple for every frame, in order,
+    with frame i+1 uploading while frame i focuses and downloads (the frame loop of sar_batch_sim.py:303-331 on host arrays).
+    `reserve` page-locked result blocks are set aside before the first frame (Context.reserve_pinned), so no call inside the loop
+    meets hipHostMalloc; a consumer that keeps more than reserve - 2 results alive at once gets fresh blocks for the rest."""
+    ctx = ctx or default_context()
+    pending = None
+    for raw in frames:
+        raw = np.asarray(raw)
+        if pending is None and reserve:
+            ctx.reserve_pinned(raw.shape, np.complex64, reserve)
+        fut = sar_focus_csa_async(raw, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
+                                  platform_speed_mps, range_ref_m, t_start_fast, ctx=ctx, **kw)
+        if pending is not None:
+            yield pending.result()
+        pending = fut
+    if pending is not None:
+        yield pending.result()
+
+
 def dpca_pulse_shift(raw_rx1, raw_rx2):
     """DPCA co-registration by one pulse (sar_ati_dcpa_sim_csa.py:402-403)."""
     return raw_rx1[1:, :], raw_rx2[:-1, :]
@@ -216,6 +280,8 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
             bufs[k] = ctx.alloc(n * 4)
         keep = set()
     d_raw = None if on_device else ctx.alloc(n * 8)
+    d_raw2 = None if on_device else ctx.alloc(n * 8)       # channel 2 uploads while channel 1 focuses: a buffer of its own
+    early = {}                                             # downloads started before the chain is complete (slc1 during channel 2's upload)
     try:
         fused = False
         have_max = False
@@ -228,11 +294,14 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
             if on_device:
                 plan.focus_dev(r1, bufs["slc1"])
             else:
-                d_raw.upload(r1)
+                # PCIe is full duplex and neither copy needs the compute units: channel 2 uploads while channel 1 focuses, and slc1
+                # (complete when channel 1's focus is) downloads while channel 2 still uploads - sar_ati_dcpa_sim_csa.py:410-411
+                d_raw.upload_unordered(r1)                  # freshly allocated: nothing enqueued touches it
                 plan.focus_dev(d_raw, bufs["slc1"])
-                ctx.sync()                                  # d_raw is about to be overwritten
-                d_raw.upload(r2)
-            src2 = r2 if on_device else d_raw
+                if not device_output:
+                    early["slc1"] = bufs["slc1"].download_begin(np.complex64, (n_az, n_rg))
+                d_raw2.upload_unordered(r2)
+            src2 = r2 if on_device else d_raw2
             if have_max and not unmasked_phase:
                 try:                                        # channel 2: the products come out of its last azimuth launch
                     plan.set_ati(bufs["slc1"], bufs["d_max"], mask_frac, cal_phase, bufs["ati_phase_masked"], bufs["slc1_mag"],
@@ -262,16 +331,26 @@ def focus_ati_dpca(raw_rx1, raw_rx2, center_wavelength_m, pulse_width_sec, chirp
         res = {"range_axis": ra, "cross_range": ca, "max_mag": max_mag, "sum_interf": sum_interf, "fused_products": fused}
         names = ["slc1"] + (["slc2"] if (return_slc2 or not fused) else []) + ["slc1_mag", "dpca_mag", "ati_phase_masked"] + \
                 (["ati_phase"] if "ati_phase" in bufs else [])
-        for k in names:
-            if device_output:
+        if device_output:
+            for k in names:
                 res[k] = bufs[k]
                 keep.add(k)
-            else:
-                res[k] = bufs[k].download(np.complex64 if k in ("slc1", "slc2") else np.float32, (n_az, n_rg)).T
+        else:                                               # every plane's download in flight at once, then collected in order
+            for k in names:
+                if k not in early:
+                    early[k] = bufs[k].download_begin(np.complex64 if k in ("slc1", "slc2") else np.float32, (n_az, n_rg))
+            for k in names:
+                res[k] = early.pop(k).result().T
         return res
     finally:
+        for pend in early.values():                         # an exception on the way: no copy may outlive the buffers released below
+            try:
+                pend.result()
+            except _ffi.SarxError:
+                pass
         for k, b in bufs.items():
             if k not in keep:
                 b.release()
-        if d_raw is not None:
-            d_raw.release()
+        for b in (d_raw, d_raw2):
+            if b is not None:
+                b.release()

@@ -1,6 +1,7 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle and the golden
 fixtures.  Tolerance from BASELINE.json's north_star: <= 1e-4 relative L2 on
 |img| and on the masked ATI phase; we also hold the complex image to 1e-4."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -737,3 +738,74 @@ def test_global_max_reduction_and_allreduce_single_rank(sx, ctx):
     ctx.lib.sarx_comm_destroy(ctx.h)
     for b in (d_x, d_y, d_m):
         b.release()
+
+
+def test_host_pipeline_bit_identical_and_bounded(sx, ctx):
+    """sarx_csa_focus_host_begin / _end, sar_focus_csa_async and focus_stream (the frame loop of sar_batch_sim.py:303-331 on host arrays,
+    frame i+1 uploading while frame i focuses and downloads): every frame bit-identical to the synchronous sar_focus_csa call, in order,
+    with pageable and page-locked results, `out=`, three frames' worth of tickets refused, and the plan usable synchronously afterwards."""
+    n_az, n_rg = 2048, 4096                                  # 64 MiB per frame: the staged copy threads and the page-locked pool are in play
+    raws, k = [], None
+    for seed in (11, 12, 13, 14, 15):
+        raw, k = orc.point_scene(n_az, n_rg, seed=seed, n_targets=3) if seed == 11 else (None, k)
+        if raw is None:
+            r = np.random.default_rng(seed)
+            raw = (r.standard_normal((n_az, n_rg), dtype=np.float32) + 1j * r.standard_normal((n_az, n_rg), dtype=np.float32)).astype(np.complex64)
+        raws.append(raw)
+    args = orc.focus_args(k)
+    ref = [sx.sar_focus_csa(r, *args, ctx=ctx)[0].copy() for r in raws]
+    assert orc.rel_l2(np.abs(ref[0]), np.abs(orc.sar_focus_csa(raws[0], *args)[0])) < TOL
+    assert ctx.reserve_pinned((n_az, n_rg), np.complex64, 3) >= 1
+    outs = list(sx.focus_stream(iter(raws), *args, ctx=ctx))
+    assert len(outs) == len(raws)
+    for i, (img, ra, ca) in enumerate(outs):
+        np.testing.assert_array_equal(img, ref[i])
+        assert img.shape == (n_rg, n_az) and ra.shape == (n_rg,) and ca.shape == (n_az,)
+    # futures by hand, two pending; a third is refused by the library (two frames per plan), and the pending ones still complete
+    f0 = sx.sar_focus_csa_async(raws[0], *args, ctx=ctx)
+    f1 = sx.sar_focus_csa_async(raws[1], *args, ctx=ctx)
+    with pytest.raises(sx.SarxError):
+        sx.sar_focus_csa_async(raws[2], *args, ctx=ctx)
+    np.testing.assert_array_equal(f1.result()[0], ref[1])    # any order
+    np.testing.assert_array_equal(f0.result()[0], ref[0])
+    assert f0.done() and f1.done()
+    np.testing.assert_array_equal(f0.result()[0], ref[0])    # result() twice: same arrays, no second wait
+    # a pageable `out` (ordinary NumPy memory): downloaded by result(), same bytes
+    mine = np.empty((n_rg, n_az), dtype=np.complex64, order="F")
+    f2 = sx.sar_focus_csa_async(raws[2], *args, ctx=ctx, out=mine)
+    got = f2.result()[0]
+    assert np.shares_memory(got, mine)
+    np.testing.assert_array_equal(got, ref[2])
+    # the synchronous call on the same cached plan afterwards
+    np.testing.assert_array_equal(sx.sar_focus_csa(raws[3], *args, ctx=ctx)[0], ref[3])
+    # C ABI argument checking
+    plan = sx.CsaPlan(ctx, 256, 256, *args)
+    t = C.c_int(7)
+    assert ctx.lib.sarx_csa_focus_host_begin(plan.h, None, None, C.byref(t)) != 0 and t.value in (-1, 7)
+    assert ctx.lib.sarx_csa_focus_host_end(plan.h, 0) != 0 and ctx.lib.sarx_csa_focus_host_end(plan.h, 5) != 0
+    slot = C.c_int(0)
+    pageable = np.empty(1024, np.uint8)
+    d = ctx.alloc(1024)
+    assert ctx.lib.sarx_memcpy_d2h_begin(ctx.h, pageable.ctypes.data, d.ptr, 1024, C.byref(slot)) != 0      # needs page-locked memory
+    assert "page-locked" in ctx.last_error()
+    assert ctx.lib.sarx_memcpy_d2h_end(ctx.h, 3) != 0
+    d.release()
+    plan.close()
+
+
+def test_two_channel_host_inputs_overlap_transfers_same_results(sx, ctx):
+    """focus_ati_dpca on HOST arrays (sar_ati_dcpa_sim_csa.py:402-419,447-449 as the script calls it): channel 2 uploads while channel 1
+    focuses, slc1 downloads meanwhile, every plane's download is in flight at once - the results equal the device-array path's."""
+    from sarx.engine import DeviceArray
+    n = 2048
+    (r1, r2), k = orc.point_scene(n, n, seed=77, two_channel=True, n_targets=4)
+    args = orc.focus_args(k)
+    host = sx.focus_ati_dpca(r1, r2, *args, ctx=ctx, pulse_shift=False)
+    d1, d2 = DeviceArray(ctx.to_device(r1), (n, n)), DeviceArray(ctx.to_device(r2), (n, n))
+    dev = sx.focus_ati_dpca(d1, d2, *args, ctx=ctx, pulse_shift=False)
+    for key in ("slc1", "slc2", "slc1_mag", "dpca_mag", "ati_phase_masked"):
+        np.testing.assert_array_equal(host[key], dev[key])
+    assert host["max_mag"] == dev["max_mag"] and host["sum_interf"] == dev["sum_interf"]
+    o1 = orc.sar_focus_csa(r1, *args)[0]
+    assert orc.rel_l2(host["slc1"], o1) < TOL
+    d1.release(); d2.release()
