@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -15,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -118,6 +121,12 @@ struct sarx_ctx {
     static constexpr size_t COPY_CHUNK = (size_t)32 << 20;
     char* pin[COPY_THREADS] = {};
     hipStream_t copy_stream[COPY_THREADS] = {};
+    hipEvent_t pin_free[COPY_THREADS] = {};     // "the DMA that last read pinned chunk i has finished"
+    int up_streams = COPY_THREADS;     // uploads issue their DMAs on this many of the copy streams (SARX_UP_STREAMS, A/B).  Beside a download in
+                                       // flight, 2 GiB each way: 67 ms with eight streams, 75 with two, 76 with one (= one after the other);
+                                       // two plain DMAs (page-locked source) 44 ms: the staged upload is bound by the HOST's memory traffic (it
+                                       // reads the array, writes the chunk, and the DMA reads the chunk again), not by the stream count
+                                       // (profiles/r05_i_duplex.log)
     std::mutex copy_mu;                // the pinned chunks and copy streams are per-ctx state: one staged copy at a time
     // overlapped host transfers (sarx_memcpy_h2d_unordered, sarx_memcpy_d2h_begin / _end): downloads run on their own stream behind an
     // event of the producing lane, uploads into free buffers do not wait for enqueued GPU work - PCIe is full duplex
@@ -183,12 +192,49 @@ static int fail(sarx_ctx* c, int code, const char* fmt, ...) {
             return fail((c), SARX_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// No C++ exception crosses the C ABI: entry points that allocate on the host (new, std::vector, std::string) run their body through
+// this guard; std::bad_alloc becomes SARX_ERR_NOMEM, anything else SARX_ERR_DEVICE, the message is set without allocating again.
+template <class F> static int guarded(sarx_ctx* c, F&& body) noexcept {
+    int code = SARX_ERR_DEVICE;
+    const char* what = "unexpected C++ exception inside libsarx";
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        code = SARX_ERR_NOMEM; what = "out of host memory";
+    } catch (...) {
+    }
+    try { if (c) c->err.assign(what); else g_init_error.assign(what); } catch (...) {}
+    return code;
+}
+
 // every lane's stream (sarx_select_lane): host-visible operations are ordered after all of them
 static hipError_t sync_all_lanes(sarx_ctx* c) {
     for (int k = 0; k < sarx_ctx::LANES; ++k)
         if (c->lane[k]) { hipError_t e = hipStreamSynchronize(c->lane[k]); if (e != hipSuccess) return e; }
     return hipSuccess;
 }
+
+// The runtime calls staged_copy makes, behind function pointers: the sanitizer build (make asan, -DSARX_TESTING) replaces them with host
+// stand-ins so that the chunking, the thread / inline-share / join logic and the error paths run under AddressSanitizer on a box
+// without a GPU (tests/asan/abi_asan_test.cpp).  The product never changes the table.
+struct CopyOps {
+    hipError_t (*memcpy_async)(void*, const void*, size_t, hipMemcpyKind, hipStream_t) = hipMemcpyAsync;
+    hipError_t (*stream_sync)(hipStream_t) = hipStreamSynchronize;
+    hipError_t (*stream_create)(hipStream_t*, unsigned) = hipStreamCreateWithFlags;
+    hipError_t (*event_create)(hipEvent_t*, unsigned) = hipEventCreateWithFlags;
+    hipError_t (*event_record)(hipEvent_t, hipStream_t) = hipEventRecord;
+    hipError_t (*event_sync)(hipEvent_t) = hipEventSynchronize;
+    hipError_t (*host_alloc)(void**, size_t, unsigned) = [](void** p, size_t n, unsigned f) { return hipHostMalloc(p, n, f); };
+    hipError_t (*set_device)(int) = hipSetDevice;
+    bool (*page_locked)(const void*) = [](const void* p) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return true;
+        (void)hipGetLastError();               // a pointer the runtime does not know is ordinary pageable memory: clear that error
+        return false;
+    };
+    bool (*may_start_thread)(int) = [](int) { return true; };     // false = behave as if std::thread threw for share i
+};
+static CopyOps g_ops;
 
 // Host <-> device copy of a large pageable buffer.  hipMemcpy from pageable memory runs at 8 GB/s here and into untouched
 // memory (a fresh NumPy array) at 13 GB/s (tools/pcibench.hip); eight threads staging 32 MiB chunks through pinned buffers reach
@@ -198,57 +244,56 @@ static hipError_t sync_all_lanes(sarx_ctx* c) {
 // ordered = false (uploads into a buffer no enqueued work touches, downloads of data already complete): the copy does not wait for
 // the lanes and runs on streams of its own, so it overlaps whatever the GPU is doing
 static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, bool narrow = false, bool ordered = true) {
-    hipError_t e = ordered ? sync_all_lanes(c) : hipSuccess;
+    const CopyOps& o = g_ops;
+    hipError_t e = hipSuccess;
+    if (ordered)
+        for (int k = 0; k < sarx_ctx::LANES && e == hipSuccess; ++k)
+            if (c->lane[k]) e = o.stream_sync(c->lane[k]);
     if (e != hipSuccess) return e;
     hipStream_t direct = c->stream;
     if (!ordered) {
-        if (!c->up_stream && (e = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        if (!c->up_stream && (e = o.stream_create(&c->up_stream, hipStreamNonBlocking)) != hipSuccess) return e;
         direct = c->up_stream;
     }
-    if (!narrow && bytes >= 4 * sarx_ctx::COPY_CHUNK) {
-        // a buffer from sarx_host_alloc (page-locked, already faulted in) needs no staging: one DMA at the PCIe rate, no host memcpy,
-        // no first touch.  A pointer the runtime does not know is ordinary pageable memory (the query fails for it: clear that error).
-        hipPointerAttribute_t at{};
-        const void* host = to_device ? src : dst;
-        if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost) {
-            e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, direct);
-            return e != hipSuccess ? e : hipStreamSynchronize(direct);
-        }
-        (void)hipGetLastError();
-    }
-    if (bytes < 4 * sarx_ctx::COPY_CHUNK && !narrow) {
-        e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, direct);
-        return e != hipSuccess ? e : hipStreamSynchronize(direct);
+    const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    // a buffer from sarx_host_alloc (page-locked, already faulted in) needs no staging: one DMA at the PCIe rate, no host memcpy,
+    // no first touch
+    if (!narrow && (bytes < 4 * sarx_ctx::COPY_CHUNK || o.page_locked(to_device ? src : dst))) {
+        e = o.memcpy_async(dst, src, bytes, kind, direct);
+        return e != hipSuccess ? e : o.stream_sync(direct);
     }
     constexpr int T = sarx_ctx::COPY_THREADS;
     constexpr size_t CH = sarx_ctx::COPY_CHUNK;
     std::lock_guard<std::mutex> lock(c->copy_mu);      // ctypes callers release the GIL: two host threads may arrive on one ctx
-    if (!c->pin[0] && (e = hipHostMalloc(&c->pin[0], CH, hipHostMallocDefault)) != hipSuccess) return e;
-    if (!c->copy_stream[0] && (e = hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking)) != hipSuccess) return e;
+    if (!c->pin[0] && (e = o.host_alloc((void**)&c->pin[0], CH, hipHostMallocDefault)) != hipSuccess) return e;
+    if (!c->copy_stream[0] && (e = o.stream_create(&c->copy_stream[0], hipStreamNonBlocking)) != hipSuccess) return e;
     if (narrow && bytes <= CH) {      // a small complex128 upload: rounded on the calling thread through one chunk, no thread is started
         const double* in = (const double*)src;
         float* out = (float*)c->pin[0];
         for (size_t k = 0; k < bytes / sizeof(float); ++k) out[k] = (float)in[k];
-        e = hipMemcpyAsync(dst, c->pin[0], bytes, hipMemcpyHostToDevice, c->copy_stream[0]);
-        return e != hipSuccess ? e : hipStreamSynchronize(c->copy_stream[0]);
+        e = o.memcpy_async(dst, c->pin[0], bytes, hipMemcpyHostToDevice, c->copy_stream[0]);
+        return e != hipSuccess ? e : o.stream_sync(c->copy_stream[0]);
     }
     for (int i = 1; i < T; ++i) {
-        if (!c->pin[i] && (e = hipHostMalloc(&c->pin[i], CH, hipHostMallocDefault)) != hipSuccess) return e;
-        if (!c->copy_stream[i] && (e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking)) != hipSuccess) return e;
+        if (!c->pin[i] && (e = o.host_alloc((void**)&c->pin[i], CH, hipHostMallocDefault)) != hipSuccess) return e;
+        if (!c->copy_stream[i] && (e = o.stream_create(&c->copy_stream[i], hipStreamNonBlocking)) != hipSuccess) return e;
     }
+    for (int i = 0; i < T; ++i)
+        if (!c->pin_free[i] && (e = o.event_create(&c->pin_free[i], hipEventDisableTiming)) != hipSuccess) return e;
+    const int US = to_device ? c->up_streams : T;       // uploads: thread i's DMAs go to copy stream i % US
     hipError_t errs[T];
     for (int i = 0; i < T; ++i) errs[i] = hipSuccess;
     std::thread th[T];                 // fixed storage: nothing here allocates, so nothing but thread creation can throw
     // thread i copies chunks i, i + T, ...; if a thread cannot be started (std::system_error must not cross the C ABI) the
     // calling thread does that share itself after the others
     auto share = [=, &errs](int i) {
-            hipError_t r = hipSetDevice(c->device);
+            hipError_t r = o.set_device(c->device);
             char* d = (char*)dst;
             const char* s0 = (const char*)src;
             for (size_t off = (size_t)i * CH; r == hipSuccess && off < bytes; off += (size_t)T * CH) {
                 const size_t len = bytes - off < CH ? bytes - off : CH;
                 if (to_device) {
-                    r = hipStreamSynchronize(c->copy_stream[i]);           // the chunk's previous DMA has left the pinned buffer
+                    if (off >= (size_t)T * CH) r = o.event_sync(c->pin_free[i]);     // the chunk's previous DMA has left the pinned buffer
                     if (r != hipSuccess) break;
                     if (narrow) {
                         const double* in = (const double*)s0 + off / sizeof(float);      // off counts complex64 bytes: 2 floats <-> 2 doubles
@@ -257,20 +302,23 @@ static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t by
                     } else {
                         memcpy(c->pin[i], s0 + off, len);
                     }
-                    r = hipMemcpyAsync(d + off, c->pin[i], len, hipMemcpyHostToDevice, c->copy_stream[i]);
+                    r = o.memcpy_async(d + off, c->pin[i], len, hipMemcpyHostToDevice, c->copy_stream[i % US]);
+                    if (r == hipSuccess) r = o.event_record(c->pin_free[i], c->copy_stream[i % US]);
                 } else {
-                    r = hipMemcpyAsync(c->pin[i], s0 + off, len, hipMemcpyDeviceToHost, c->copy_stream[i]);
-                    if (r == hipSuccess) r = hipStreamSynchronize(c->copy_stream[i]);
+                    r = o.memcpy_async(c->pin[i], s0 + off, len, hipMemcpyDeviceToHost, c->copy_stream[i]);
+                    if (r == hipSuccess) r = o.stream_sync(c->copy_stream[i]);
                     if (r == hipSuccess) memcpy(d + off, c->pin[i], len);
                 }
             }
-            if (r == hipSuccess) r = hipStreamSynchronize(c->copy_stream[i]);
+            if (r == hipSuccess) r = to_device ? o.event_sync(c->pin_free[i]) : o.stream_sync(c->copy_stream[i]);
             errs[i] = r;
         };
     bool inline_share[T] = {};
     for (int i = 0; i < T; ++i) {
-        try { th[i] = std::thread(share, i); }
-        catch (...) { inline_share[i] = true; }          // std::system_error / std::bad_alloc: no exception crosses the C ABI
+        try {
+            if (!o.may_start_thread(i)) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+            th[i] = std::thread(share, i);
+        } catch (...) { inline_share[i] = true; }        // std::system_error / std::bad_alloc: no exception crosses the C ABI
     }
     for (int i = 0; i < T; ++i) if (inline_share[i]) share(i);
     for (int i = 0; i < T; ++i) if (th[i].joinable()) th[i].join();     // every started thread is joined on the one exit path
@@ -297,7 +345,7 @@ int sarx_device_count(int* out_count) {
     return SARX_OK;
 }
 
-int sarx_init(int device_id, sarx_ctx** out_ctx) {
+static int sarx_init_impl(int device_id, sarx_ctx** out_ctx) {
     if (!out_ctx) return fail(nullptr, SARX_ERR_INVALID, "out_ctx is NULL");
     *out_ctx = nullptr;
     int n = 0;
@@ -316,6 +364,7 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
     if (prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
     if (const char* e2 = getenv("SARX_RANGE_IMPL")) c->range_impl = (e2[0] == 'v') ? atoi(e2 + 1) : atoi(e2);
     if (const char* e2 = getenv("SARX_RANGE_CUS")) c->range_cus = atoi(e2);
+    if (const char* e2 = getenv("SARX_UP_STREAMS")) { const int v = atoi(e2); if (v >= 1 && v <= sarx_ctx::COPY_THREADS) c->up_streams = v; }
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->lane[0] = c->stream;
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
@@ -340,6 +389,9 @@ int sarx_init(int device_id, sarx_ctx** out_ctx) {
     *out_ctx = c;
     return SARX_OK;
 }
+int sarx_init(int device_id, sarx_ctx** out_ctx) {
+    return guarded(nullptr, [&] { return sarx_init_impl(device_id, out_ctx); });
+}
 
 int sarx_destroy(sarx_ctx* c) {
     if (!c) return SARX_OK;
@@ -354,6 +406,7 @@ int sarx_destroy(sarx_ctx* c) {
     for (int i = 0; i < sarx_ctx::COPY_THREADS; ++i) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
         if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
+        if (c->pin_free[i]) hipEventDestroy(c->pin_free[i]);
     }
     for (int i = 0; i < sarx_ctx::DL_SLOTS; ++i) {
         if (c->dl_ready[i]) hipEventDestroy(c->dl_ready[i]);
@@ -426,12 +479,7 @@ int sarx_memcpy_h2d_unordered(sarx_ctx* c, void* d, const void* s, size_t n) {
     HIPCHK(c, staged_copy(c, d, s, n, true, false, /*ordered=*/false));
     return SARX_OK;
 }
-static bool is_page_locked(const void* p) {
-    hipPointerAttribute_t at{};
-    if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return true;
-    (void)hipGetLastError();
-    return false;
-}
+static bool is_page_locked(const void* p) { return g_ops.page_locked(p); }
 int sarx_memcpy_d2h_begin(sarx_ctx* c, void* h, const void* d, size_t n, int* out_slot) {
     NEED_CTX(c);
     if (!h || !d || !out_slot) return fail(c, SARX_ERR_INVALID, "NULL pointer");
@@ -559,7 +607,7 @@ int sarx_event_elapsed_ms(sarx_ctx* c, int a, int b, float* ms) {
 }
 
 // ---- CSA plan -----------------------------------------------------------------
-int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_params* prm, unsigned flags, sarx_plan** out) {
+static int sarx_csa_plan_create_impl(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_params* prm, unsigned flags, sarx_plan** out) {
     NEED_CTX(c);
     if (!out || !prm) return fail(c, SARX_ERR_INVALID, "NULL argument");
     *out = nullptr;
@@ -639,6 +687,9 @@ int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_param
     }
     *out = p;
     return SARX_OK;
+}
+int sarx_csa_plan_create(sarx_ctx* c, int n_az, int n_rg, const sarx_radar_params* prm, unsigned flags, sarx_plan** out) {
+    return guarded(c, [&] { return sarx_csa_plan_create_impl(c, n_az, n_rg, prm, flags, out); });
 }
 
 int sarx_csa_plan_destroy(sarx_plan* p) {
@@ -1095,7 +1146,7 @@ struct sarx_rda_plan {
     float2* d_in = nullptr;
 };
 
-int sarx_rda_plan_create(sarx_ctx* c, int n_ranges, int n_pulses, const sarx_radar_params* prm, sarx_rda_plan** out) {
+static int sarx_rda_plan_create_impl(sarx_ctx* c, int n_ranges, int n_pulses, const sarx_radar_params* prm, sarx_rda_plan** out) {
     NEED_CTX(c);
     if (!out || !prm) return fail(c, SARX_ERR_INVALID, "NULL argument");
     *out = nullptr;
@@ -1113,6 +1164,9 @@ int sarx_rda_plan_create(sarx_ctx* c, int n_ranges, int n_pulses, const sarx_rad
     if (e != hipSuccess) { rda_destroy(r); delete p; return fail(c, SARX_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
     *out = p;
     return SARX_OK;
+}
+int sarx_rda_plan_create(sarx_ctx* c, int n_ranges, int n_pulses, const sarx_radar_params* prm, sarx_rda_plan** out) {
+    return guarded(c, [&] { return sarx_rda_plan_create_impl(c, n_ranges, n_pulses, prm, out); });
 }
 int sarx_rda_plan_destroy(sarx_rda_plan* p) {
     if (!p) return SARX_OK;
@@ -1311,7 +1365,7 @@ struct sarx_tdbp_plan {
     float2* d_raw = nullptr;       // staging for the host entry point
 };
 
-int sarx_tdbp_plan_create(sarx_ctx* c, int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp_params* k,
+static int sarx_tdbp_plan_create_impl(sarx_ctx* c, int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp_params* k,
                           sarx_tdbp_plan** out) {
     NEED_CTX(c);
     if (!out || !k) return fail(c, SARX_ERR_INVALID, "NULL argument");
@@ -1327,6 +1381,10 @@ int sarx_tdbp_plan_create(sarx_ctx* c, int n_pulses, int num_samples, int nx, in
     p->ctx = c; p->t = t; p->n_p = n_pulses; p->n_s = num_samples; p->nx = nx; p->ny = ny;
     *out = p;
     return SARX_OK;
+}
+int sarx_tdbp_plan_create(sarx_ctx* c, int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp_params* k,
+                          sarx_tdbp_plan** out) {
+    return guarded(c, [&] { return sarx_tdbp_plan_create_impl(c, n_pulses, num_samples, nx, ny, k, out); });
 }
 int sarx_tdbp_plan_destroy(sarx_tdbp_plan* p) {
     if (!p) return SARX_OK;
@@ -1399,7 +1457,7 @@ int sarx_add_ocean_noise_rel_dev(sarx_ctx* c, void* buf, size_t n, int ref_is_ma
     HIPCHK(c, launch_ocean_noise((float2*)buf, n, 0.f, 0.f, (float)k_nu, seed, c->stream, d_levels));
     return SARX_OK;
 }
-int sarx_power_stats_dev(sarx_ctx* c, const void* buf, size_t n, double* max_abs2, double* mean_abs2) {
+static int sarx_power_stats_dev_impl(sarx_ctx* c, const void* buf, size_t n, double* max_abs2, double* mean_abs2) {
     NEED_CTX(c);
     if (!buf || !n) return fail(c, SARX_ERR_INVALID, "empty buffer");
     const int blocks = 1024;
@@ -1414,6 +1472,9 @@ int sarx_power_stats_dev(sarx_ctx* c, const void* buf, size_t n, double* max_abs
     if (max_abs2) *max_abs2 = mx;
     if (mean_abs2) *mean_abs2 = sum / (double)n;
     return SARX_OK;
+}
+int sarx_power_stats_dev(sarx_ctx* c, const void* buf, size_t n, double* max_abs2, double* mean_abs2) {
+    return guarded(c, [&] { return sarx_power_stats_dev_impl(c, buf, n, max_abs2, mean_abs2); });
 }
 
 // ---- RCCL ------------------------------------------------------------------------
@@ -1494,5 +1555,61 @@ int sarx_comm_destroy(sarx_ctx* c) {
     if (c->comm) { hipStreamSynchronize(c->comm_stream); g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     return SARX_OK;
 }
+
+
+#ifdef SARX_TESTING
+// ---- sanitizer-build hook (make asan; never part of libsarx.so) -----------------------------------------------------------------
+// staged_copy on a stand-in context with host stand-ins for the runtime: "device" memory is host memory, a DMA is a memcpy, streams
+// and events are opaque tokens.  no_thread_mask: bit i = share i's thread "cannot be started" (the inline-share path);
+// fail_at >= 0: the fail_at-th copy call returns an error (every thread must still be joined, the error returned);
+// page_locked != 0: the host side counts as page-locked (the one-DMA path).  Returns staged_copy's hipError_t as an int.
+static std::atomic<int> t_copy_calls{0};
+static int t_fail_at = -1;
+static unsigned t_no_thread = 0;
+static int t_locked = 0;
+static std::atomic<int> t_tokens{0};
+int sarx_test_staged_copy(void* dst, const void* src, size_t bytes, int to_device, int narrow, int ordered, unsigned no_thread_mask,
+                          int fail_at, int page_locked, int up_streams, int* threads_inline) {
+    CopyOps saved = g_ops;
+    t_copy_calls = 0; t_fail_at = fail_at; t_no_thread = no_thread_mask; t_locked = page_locked;
+    g_ops.memcpy_async = [](void* d, const void* s2, size_t n, hipMemcpyKind, hipStream_t st) {
+        if (!st) return hipErrorInvalidHandle;
+        if (t_copy_calls.fetch_add(1) == t_fail_at) return hipErrorUnknown;
+        memcpy(d, s2, n);
+        return hipSuccess;
+    };
+    g_ops.stream_sync = [](hipStream_t st) { return st ? hipSuccess : hipErrorInvalidHandle; };
+    g_ops.stream_create = [](hipStream_t* st, unsigned) { *st = (hipStream_t)(uintptr_t)(0x1000 + 16 * t_tokens.fetch_add(1)); return hipSuccess; };
+    g_ops.event_create = [](hipEvent_t* ev, unsigned) { *ev = (hipEvent_t)(uintptr_t)(0x100000 + 16 * t_tokens.fetch_add(1)); return hipSuccess; };
+    g_ops.event_record = [](hipEvent_t ev, hipStream_t st) { return (ev && st) ? hipSuccess : hipErrorInvalidHandle; };
+    g_ops.event_sync = [](hipEvent_t ev) { return ev ? hipSuccess : hipErrorInvalidHandle; };
+    g_ops.host_alloc = [](void** p2, size_t n, unsigned) { *p2 = malloc(n); return *p2 ? hipSuccess : hipErrorOutOfMemory; };
+    g_ops.set_device = [](int) { return hipSuccess; };
+    g_ops.page_locked = [](const void*) { return t_locked != 0; };
+    g_ops.may_start_thread = [](int i) { return !((t_no_thread >> i) & 1u); };
+    int rc;
+    {
+        sarx_ctx c;
+        c.device = 0;
+        c.stream = (hipStream_t)(uintptr_t)0x10;
+        c.lane[0] = c.stream;
+        if (up_streams >= 1 && up_streams <= sarx_ctx::COPY_THREADS) c.up_streams = up_streams;
+        rc = (int)staged_copy(&c, dst, src, bytes, to_device != 0, narrow != 0, ordered != 0);
+        if (threads_inline) { int k = 0; for (int i = 0; i < sarx_ctx::COPY_THREADS; ++i) k += (no_thread_mask >> i) & 1u; *threads_inline = k; }
+        for (int i = 0; i < sarx_ctx::COPY_THREADS; ++i) free(c.pin[i]);
+    }
+    g_ops = saved;
+    return rc;
+}
+size_t sarx_test_copy_chunk(void) { return sarx_ctx::COPY_CHUNK; }
+int sarx_test_copy_threads(void) { return sarx_ctx::COPY_THREADS; }
+int sarx_test_guard(int what) {      // the exception guard of the allocating entry points: 0 ok, 1 bad_alloc, 2 any other exception
+    return guarded(nullptr, [&]() -> int {
+        if (what == 1) throw std::bad_alloc();
+        if (what == 2) throw std::runtime_error("x");
+        return SARX_OK;
+    });
+}
+#endif
 
 }  // extern "C"
