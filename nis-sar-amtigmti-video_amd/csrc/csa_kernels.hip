@@ -2,7 +2,6 @@
 // passes, each an FFT fused with the phase multiply that follows it in the
 // reference (sar_ati_dcpa_sim_csa.py:233-385).  fftshift/ifftshift pairs of the
 // reference cancel: phases are evaluated at natural-order bins.
-#include <cstdlib>
 #include <type_traits>
 #include "csa_kernels.h"
 #include "fft_core.hpp"
@@ -23,11 +22,12 @@ template <int N> struct RangeCfg {
     static constexpr size_t LDS_BYTES = (size_t)ROWS * LDS_PER_ROW * sizeof(cf);
 };
 
-template <int N, int MODE, bool PLANES>
-__device__ __forceinline__ void range_pass_body(const RangeArgs& a, char* smem_raw) {
+template <int N, int MODE>
+__global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeArgs a) {
     using CFG = RangeCfg<N>;
     using PL = Plan<N>;
     constexpr int P = PL::P, T = PL::T;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);
 
     const int r_in_wg = threadIdx.x / T;
@@ -36,7 +36,7 @@ __device__ __forceinline__ void range_pass_body(const RangeArgs& a, char* smem_r
     const bool live = line < a.n_az;
     if (!live) line = a.n_az - 1;                   // keep barriers uniform
     const int row = range_row(a, line);
-    cf* my_lds = PLANES ? reinterpret_cast<cf*>(reinterpret_cast<float*>(lds) + r_in_wg * CFG::LDS_PER_ROW) : lds + r_in_wg * CFG::LDS_PER_ROW;
+    cf* my_lds = lds + r_in_wg * CFG::LDS_PER_ROW;
     const cf* __restrict__ src = a.in + (size_t)row * N;
     cf* __restrict__ dst = a.out + (size_t)row * N;
 
@@ -54,7 +54,7 @@ __device__ __forceinline__ void range_pass_body(const RangeArgs& a, char* smem_r
         for (int b = 0; b < P / R0; ++b)
 #pragma unroll
             for (int r = 0; r < R0; ++r) v[b * R0 + r] = src[E::in_index(t, b, r)];
-        stockham_run<N, 1, false, false, 0, false, PLANES>(v, t, 0, my_lds, a.tw);
+        stockham_run<N, 1, false, false>(v, t, 0, my_lds, a.tw);
         constexpr int RL = E::R_last;
         if constexpr (MODE == RG_FFT) {
             if (live) {
@@ -107,7 +107,7 @@ __device__ __forceinline__ void range_pass_body(const RangeArgs& a, char* smem_r
     } else {
         __syncthreads();      // forward half's last gather finished before the image is reused
     }
-    stockham_run<N, 1, true, REV, 0, false, PLANES>(v, t, 0, my_lds, a.tw);
+    stockham_run<N, 1, true, REV>(v, t, 0, my_lds, a.tw);
     constexpr int RL = EI::R_last;
     const float s = a.inv_n;
     if constexpr (MODE == RG_IFFT) {
@@ -133,20 +133,6 @@ __device__ __forceinline__ void range_pass_body(const RangeArgs& a, char* smem_r
     }
 }
 
-template <int N, int MODE>
-__global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    range_pass_body<N, MODE, false>(a, smem_raw);
-}
-// Round 5: the exchanges one component at a time through a float image of half the bytes, 80 VGPRs, so that THREE
-// 512-thread workgroups (24 waves, six per SIMD) share a CU where two did: more lines in flight per CU to cover the 0.10 ms of exposed
-// memory of the 8192-sample fused launch.  SARX_RANGE_PLANES=1 selects it for the A/B.
-template <int N, int MODE>
-__global__ __launch_bounds__(RangeCfg<N>::THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void range_pass_planes_kernel(RangeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    range_pass_body<N, MODE, true>(a, smem_raw);
-}
-
 // One workgroup per line group, not persistent: a persistent form of this kernel (2 workgroups per CU walking the lines, <= 128
 // VGPRs, no scratch) ran 8192-sample lines 3-12 % SLOWER in every mode (fused 0.362-0.376 vs 0.348-0.351 ms, FFT+Phi2 0.244-0.250
 // vs 0.216-0.220 ms at 8192 x 8192; profiles/r03_p_range_persistent_ab.log, ABBA order) - with a few waves per line a fresh
@@ -160,13 +146,6 @@ template <int N, int MODE> static hipError_t launch_range(const RangeArgs& a, hi
         if (e != hipSuccess) return e;
     }
     const int grid = (a.n_az + CFG::ROWS - 1) / CFG::ROWS;
-    if constexpr (N == 8192 && MODE == RG_FUSED) {
-        static const int planes = [] { const char* e = getenv("SARX_RANGE_PLANES"); return e ? atoi(e) : 0; }();
-        if (planes) {
-            hipLaunchKernelGGL((range_pass_planes_kernel<N, MODE>), dim3(grid), dim3(CFG::THREADS), CFG::LDS_BYTES / 2, st, a);
-            return hipGetLastError();
-        }
-    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(CFG::THREADS), CFG::LDS_BYTES, st, a);
     return hipGetLastError();
 }

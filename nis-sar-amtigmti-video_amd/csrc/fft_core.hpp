@@ -278,35 +278,6 @@ __device__ __forceinline__ void stage_gather(cf* v, int t, int c, const cf* lds)
     }
 }
 
-// The same exchange one component (re, then im) at a time through a FLOAT image of half the bytes (range lines only, W == 1): more
-// workgroups fit a CU's LDS at the price of twice the LDS instructions and two more barriers per exchange.
-template <int N, int T, int R, int NS, int COMP>
-__device__ __forceinline__ void stage_scatter_plane(const cf* v, int t, float* lds) {
-    constexpr int P = N / T;
-    constexpr int B = P / R;
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const int j = t + b * T;
-        const int base = (j / NS) * (NS * R) + (j % NS);
-#pragma unroll
-        for (int r = 0; r < R; ++r) lds[lds_index<1>(base + r * NS, 0)] = COMP ? v[b * R + r].y : v[b * R + r].x;
-    }
-}
-template <int N, int T, int R, int COMP>
-__device__ __forceinline__ void stage_gather_plane(cf* v, int t, const float* lds) {
-    constexpr int P = N / T;
-    constexpr int B = P / R;
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const int j = t + b * T;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float f = lds[lds_index<1>(j + r * (N / R), 0)];
-            if (COMP) v[b * R + r].y = f; else v[b * R + r].x = f;
-        }
-    }
-}
-
 // Runs stages S..nstages-1 of Plan<N> (order REV) on registers that already
 // hold stage S's inputs.  Leaves the last stage's outputs in v: butterfly b,
 // point r is output index  (t + b*T) + r*(N/Rlast).
@@ -323,32 +294,20 @@ template <bool WAVE_LOCAL> __device__ __forceinline__ void exchange_sync() {
         __syncthreads();
     }
 }
-template <int N, int W, bool INV, bool REV, int S = 0, bool WAVE_LOCAL = false, bool PLANES = false>
+template <int N, int W, bool INV, bool REV, int S = 0, bool WAVE_LOCAL = false>
 __device__ __forceinline__ void stockham_run(cf* v, int t, int c, cf* lds, const cf* __restrict__ tw) {
     using PL = Plan<N>;
     static_assert(!WAVE_LOCAL || PL::T == 64, "wave-local transforms span exactly one wavefront");
-    static_assert(!PLANES || (W == 1 && !WAVE_LOCAL), "component planes: range lines, workgroup-wide exchanges");
     constexpr int R = PL::template radix<REV>(S);
     constexpr int NS = PL::template ns_before<REV>(S);
     stage_compute<N, PL::T, R, NS, INV>(v, t, tw);
     if constexpr (S + 1 < PL::nstages) {
         constexpr int R2 = PL::template radix<REV>(S + 1);
         if constexpr (S > 0) exchange_sync<WAVE_LOCAL>();   // previous gather done before overwrite
-        if constexpr (PLANES) {
-            float* ldsf = reinterpret_cast<float*>(lds);
-            stage_scatter_plane<N, PL::T, R, NS, 0>(v, t, ldsf);
-            __syncthreads();
-            stage_gather_plane<N, PL::T, R2, 0>(v, t, ldsf);     // the new re lands while the old im still waits to be written
-            __syncthreads();
-            stage_scatter_plane<N, PL::T, R, NS, 1>(v, t, ldsf);
-            __syncthreads();
-            stage_gather_plane<N, PL::T, R2, 1>(v, t, ldsf);
-        } else {
-            stage_scatter<N, PL::T, R, NS, W>(v, t, c, lds);
-            exchange_sync<WAVE_LOCAL>();
-            stage_gather<N, PL::T, R2, W>(v, t, c, lds);
-        }
-        stockham_run<N, W, INV, REV, S + 1, WAVE_LOCAL, PLANES>(v, t, c, lds, tw);
+        stage_scatter<N, PL::T, R, NS, W>(v, t, c, lds);
+        exchange_sync<WAVE_LOCAL>();
+        stage_gather<N, PL::T, R2, W>(v, t, c, lds);
+        stockham_run<N, W, INV, REV, S + 1, WAVE_LOCAL>(v, t, c, lds, tw);
     }
 }
 

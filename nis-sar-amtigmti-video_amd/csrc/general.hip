@@ -756,11 +756,6 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
         // convolution when the wrapped ends miss it: M >= full - c0 and M >= c0 + n_r
         const int c0 = (l_mf - 1) / 2, full = n_r + l_mf - 1, m_need = std::max(full - c0, c0 + n_r);
         if (direct && m_c > 16384 && range_conv_supported(19683) && m_need <= 19683 && n_r <= 19683) r->m_conv = 19683;
-        if (r->m_conv) {             // A/B of the circular length (round 5): SARX_CONV_M=19200 (32 . 24 . 25) or 19201 (25 . 24 . 32 on 19200 points)
-            const char* me = getenv("SARX_CONV_M");
-            const int mm = me ? atoi(me) : 0, len = mm == 19201 ? 19200 : mm;
-            if (mm && range_conv_supported(mm) && m_need <= len && n_r <= len) r->m_conv = mm;
-        }
         r->pfa72 = direct && az_pfa7200_supported(n_p);
     }
     r->g = general_csa_create(n_p, n_r, prm, tw_all, err, false, r->cus);      // buffers and the azimuth axis only
@@ -792,7 +787,7 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     nrm = sqrt(nrm);
     for (int k = 0; k < l_mf; ++k) h[k] /= nrm;
     if (r->m_conv) {                 // the same taps at the circular length of the direct kernel
-        std::vector<zd> hc(r->m_conv == 19201 ? 19200 : r->m_conv, zd(0, 0));
+        std::vector<zd> hc(r->m_conv, zd(0, 0));
         for (int k = 0; k < l_mf; ++k) hc[k] = h[k];
         host_dft_any(hc);
         if ((e = upload(hc, &r->hhat_conv)) != hipSuccess) return bail("upload filter", e);
@@ -862,7 +857,7 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out,
     if (r->m_conv) {
         // one launch: zero-padded FFT . filter spectrum . IFFT of every pulse at the circular length, 'same' window out (:388-392)
         RangeArgs ca{};
-        ca.in = d_in; ca.out = r->pc; ca.n_az = n_p; ca.inv_n = 1.0f / (float)(r->m_conv == 19201 ? 19200 : r->m_conv); ca.mulvec = r->hhat_conv; ca.mul_period = 1;
+        ca.in = d_in; ca.out = r->pc; ca.n_az = n_p; ca.inv_n = 1.0f / (float)r->m_conv; ca.mulvec = r->hhat_conv; ca.mul_period = 1;
         ca.conv_valid = n_r; ca.conv_crop0 = (r->l_mf - 1) / 2; ca.conv_out = n_r; ca.conv_in_ld = (size_t)n_r; ca.conv_out_ld = (size_t)n_r;
         GCK(launch_range_conv(r->m_conv, ca, r->cus, st));
     } else {

@@ -40,10 +40,9 @@ namespace sarx {
 // conflict-free LDS cycles on the strided reads of crossing 1, about 3 us of LDS time per 13200-sample line in all).
 // NPF_: how many of the R1 first-stage samples per thread are prefetched for the next line (the rest is loaded at the top of the line)
 // PLANES_: the crossings move re and im separately through a float image (half the bytes: two workgroups per CU), no prefetch
-template <int N_, int R1_, int R2_, int R3_, int T_, int P1_, int P2_, int P3_, int P4_, int NPF_ = R1_, bool PLANES_ = false, int FLAGS_ = 0> struct MixCfg {
+template <int N_, int R1_, int R2_, int R3_, int T_, int P1_, int P2_, int P3_, int P4_, int NPF_ = R1_, bool PLANES_ = false> struct MixCfg {
     static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_, T = T_, NPF = NPF_;
     static constexpr bool PLANES = PLANES_;
-    static constexpr bool NO_TWIDDLES = (FLAGS_ & 1) != 0;      // timing ablation only (wrong results): the stages without their inter-stage twiddles = what a prime-factor map would leave
     static_assert(R1 * R2 * R3 == N, "radices must multiply to the line length");
     static_assert(N / R1 <= T && N / R2 <= T && N / R3 <= T, "one butterfly per thread and stage");
     static constexpr int RMAX = (R1 > R2 ? (R1 > R3 ? R1 : R3) : (R2 > R3 ? R2 : R3));
@@ -131,7 +130,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
     // pipe idles through the whole transform.  The next line's R1 first-stage samples per thread wait in registers instead,
     // requested in two bursts during the inverse half (after the mid-line vector loads of RG_CONV's filter spectrum: vmcnt
     // retires in order, a load issued behind the prefetch would wait for all of it).
-    constexpr bool PRE = MIX_PREFETCH && FWD && BWD && !PL && C::NPF > 0;
+    constexpr bool PRE = MIX_PREFETCH && FWD && BWD && !PL;
     const size_t in_ld = (MODE == RG_CONV) ? a.conv_in_ld : (size_t)N;
     auto load_first_stage = [&](cf* dstv, const cf* p, int t, int r0, int r1) {
 #pragma unroll
@@ -205,7 +204,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                   nothing);
             // stage 2: radix R2, NS = R1
             if (t < G2) {
-                if constexpr (!C::NO_TWIDDLES) mix_twiddle<R2, R1, false>(v, t);
+                mix_twiddle<R2, R1, false>(v, t);
                 mix::dft_any<R2, false>(v);
             }
             __syncthreads();                            // every read of the image is finished
@@ -217,7 +216,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                   nothing);
             // stage 3: radix R3, NS = R1 R2; thread t ends with bins k = t + r G3
             if (t < G3) {
-                if constexpr (!C::NO_TWIDDLES) mix_twiddle<R3, R1 * R2, false>(v, t);
+                mix_twiddle<R3, R1 * R2, false>(v, t);
                 mix::dft_any<R3, false>(v);
                 if constexpr (MODE == RG_CONV) {      // times the filter spectrum, bins k = t + r G3 (the inverse starts from these registers)
                     const cf* __restrict__ mv = a.mulvec;
@@ -266,7 +265,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                   [&] { if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, 0, NPF / 2); } });
             // stage 2: radix R2, NS = R3
             if (t < G2) {
-                if constexpr (!C::NO_TWIDDLES) mix_twiddle<R2, R3, true>(v, t);
+                mix_twiddle<R2, R3, true>(v, t);
                 mix::dft_any<R2, true>(v);
             }
             __syncthreads();
@@ -278,7 +277,7 @@ __device__ __forceinline__ void range_mixed_body(const RangeArgs& a, char* smem_
                   [&] { if constexpr (PRE) { if (t < G1) load_first_stage(nxt, nsrc, t, NPF / 2, NPF); } });
             // stage 3: radix R1, NS = R3 R2; thread t ends with samples n = t + r G1
             if (t < G1) {
-                if constexpr (!C::NO_TWIDDLES) mix_twiddle<R1, R3 * R2, true>(v, t);
+                mix_twiddle<R1, R3 * R2, true>(v, t);
                 mix::dft_any<R1, true>(v);
                 const float s = a.inv_n;
                 if constexpr (MODE == RG_CONV) {      // only the cropped window is written
@@ -332,24 +331,6 @@ using Mix13200P = MixCfg<13200, 24, 22, 25, 640, 0, 8, 25, 19, 24, true>;
 // 77 KiB image, 80 VGPRs - spills 224 B per lane and takes the RDA focus from 2.13 to 3.02 ms: profiles/r04_n_rda_planes_and_lanes.log.)
 using Mix19683 = MixCfg<19683, 27, 27, 27, 768, 0, 2, 0, 2, 19>;     // 19 of the 27 rows prefetched: every row a 13200-sample line has samples in (27 rows spill at 168 VGPRs)
 
-// Round 5, VERDICT item 1b (the 16 . 33 . 25 prime-factor split): its thread structure measured on THIS kernel before any index map is
-// written - Mix13200pfa runs the same three radices with Cooley-Tukey twiddles (correct results), Mix13200pfa0 drops the twiddles
-// (wrong results, timing only): what a Good-Thomas map could at best leave of the launch, its Phi_2 fold and first-stage fix not yet
-// charged.  825 / 400 / 528 butterflies per stage on thirteen waves.  Mix13200b: the balanced alternative 20 . 22 . 30 (660 / 600 / 440).
-using Mix13200pfa = MixCfg<13200, 16, 33, 25, 832, 1, 0, 1, 0, 0>;
-using Mix13200pfa0 = MixCfg<13200, 16, 33, 25, 832, 1, 0, 1, 0, 0, false, 1>;
-using Mix13200b = MixCfg<13200, 20, 22, 30, 704, 2, 12, 1, 10, 0>;
-using Mix13200b0 = MixCfg<13200, 20, 22, 30, 704, 2, 12, 1, 10, 0, false, 1>;
-using Mix13200bP = MixCfg<13200, 20, 22, 30, 704, 2, 28, 2, 10, 20, true>;          // 20 . 22 . 30 through re / im planes, two workgroups per CU (22 waves)
-using Mix13200n0 = MixCfg<13200, 24, 22, 25, 640, 0, 8, 25, 19, 24, true, 1>;     // the shipping planes form without twiddles
-
-// 19200 = 32 * 24 * 25 (round 5): the SHORTEST circular length that holds the 'same' window, on cheaper butterflies than 27^3 (a 32-point
-// power-of-two stage; 117 against 152 vector instructions per point and direction by the count of DESIGN 4.6) - but its middle stage has 800
-// butterflies: thirteen waves, four on one SIMD, 128 VGPRs, so no register prefetch (NPF = 0).  Both stage orders are built for the A/B
-// (SARX_CONV_M=19200 / 19201 = the 25 . 24 . 32 order); pads from tools/lds_layout_sim.py 19200 32 24 25 832.
-using Mix19200 = MixCfg<19200, 32, 24, 25, 832, 1, 0, 9, 1, 0>;
-using Mix19200r = MixCfg<19200, 25, 24, 32, 832, 9, 1, 1, 0, 0>;
-
 template <class C, int MODE> static hipError_t launch_mixed(const RangeArgs& a, int cus, hipStream_t st) {
     void (*k)(RangeArgs);
     if constexpr (C::PLANES) k = range_mixed_planes_kernel<C, MODE>; else k = range_mixed_kernel<C, MODE>;
@@ -376,14 +357,11 @@ bool range_mixed_supported(int n_rg) { return n_rg == 13200; }
 
 // circular convolution of every line with the filter whose m-point spectrum (natural bin order, NOT divided by m) is
 // a.mulvec: a.conv_* describe the zero padding and the crop.  m = 19683 only.
-bool range_conv_supported(int m) { return m == 19683 || m == 19200 || m == 19201; }     // 19201: 19200 points in the 25 . 24 . 32 stage order
+bool range_conv_supported(int m) { return m == 19683; }
 hipError_t launch_range_conv(int m, const RangeArgs& a, int cus, hipStream_t st) {
-    const int len = m == 19201 ? 19200 : m;
-    if (!range_conv_supported(m) || !a.mulvec || a.conv_valid <= 0 || a.conv_crop0 < 0 || a.conv_out <= 0 ||
-        a.conv_crop0 + a.conv_out > len || a.conv_valid > len)
+    if (m != 19683 || !a.mulvec || a.conv_valid <= 0 || a.conv_valid > m || a.conv_crop0 < 0 || a.conv_out <= 0 ||
+        a.conv_crop0 + a.conv_out > m)
         return hipErrorInvalidValue;
-    if (m == 19200) return launch_mixed<Mix19200, RG_CONV>(a, cus, st);
-    if (m == 19201) return launch_mixed<Mix19200r, RG_CONV>(a, cus, st);
     return launch_mixed<Mix19683, RG_CONV>(a, cus, st);
 }
 
@@ -392,13 +370,6 @@ hipError_t launch_range_mixed(int n_rg, int mode, const RangeArgs& a, int cus, h
         case 13200: {
             // fused launch at 7199 x 13200: 0.635 -> 0.595 ms with two workgroups per CU (profiles/r03_v_range_mixed_planes.log; SARX_MIXED_PLANES=0 for A/B)
             static const int planes = [] { const char* e = getenv("SARX_MIXED_PLANES"); return e ? atoi(e) : 1; }();
-            static const int variant = [] { const char* e = getenv("SARX_MIX_VARIANT"); return e ? atoi(e) : 0; }();   // round-5 A/B, fused mode only
-            if (mode == RG_FUSED && variant == 1) return launch_mixed<Mix13200pfa, RG_FUSED>(a, cus, st);
-            if (mode == RG_FUSED && variant == 2) return launch_mixed<Mix13200pfa0, RG_FUSED>(a, cus, st);
-            if (mode == RG_FUSED && variant == 3) return launch_mixed<Mix13200b, RG_FUSED>(a, cus, st);
-            if (mode == RG_FUSED && variant == 4) return launch_mixed<Mix13200b0, RG_FUSED>(a, cus, st);
-            if (mode == RG_FUSED && variant == 5) return launch_mixed<Mix13200n0, RG_FUSED>(a, cus, st);
-            if (mode == RG_FUSED && variant == 6) return launch_mixed<Mix13200bP, RG_FUSED>(a, cus, st);
             if (planes && mode == RG_FUSED) return launch_mixed<Mix13200P, RG_FUSED>(a, cus, st);
             return launch_mixed_mode<Mix13200>(mode, a, cus, st);
         }

@@ -495,7 +495,13 @@ int sarx_memcpy_d2h_begin(sarx_ctx* c, void* h, const void* d, size_t n, int* ou
     if (!c->dl_done[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->dl_done[slot], hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->dl_ready[slot], c->stream));              // everything enqueued on the current lane so far
     HIPCHK(c, hipStreamWaitEvent(c->dl_stream, c->dl_ready[slot], 0));
-    if (n) HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->dl_stream));
+    {   // in pieces (SARX_DL_CHUNK_MIB, A/B): does one 2 GiB download hold up the upload's 32 MiB DMAs more than many small ones?
+        // beside a staged upload 2 GiB as one DMA took 65.9 ms for both, in 32 MiB pieces 62.9, in 256 MiB pieces 59.0 (profiles/r05_i_duplex.log)
+        static const size_t piece = [] { const char* e = getenv("SARX_DL_CHUNK_MIB"); return (size_t)(e ? atoi(e) : 256) << 20; }();
+        const size_t step = piece ? piece : n;
+        for (size_t off = 0; off < n; off += step)
+            HIPCHK(c, hipMemcpyAsync((char*)h + off, (const char*)d + off, n - off < step ? n - off : step, hipMemcpyDeviceToHost, c->dl_stream));
+    }
     HIPCHK(c, hipEventRecord(c->dl_done[slot], c->dl_stream));
     c->dl_busy[slot] = true;
     *out_slot = slot;
