@@ -706,6 +706,8 @@ int sarx_csa_plan_destroy(sarx_plan* p) {
     hipFree(p->c1); hipFree(p->c2); hipFree(p->c3);
     hipFree(p->ati_part);
     hipFree(p->buf_a); hipFree(p->buf_b); hipFree(p->h_in); hipFree(p->h_out); hipFree(p->look_part);
+    for (int i = 0; i < sarx_plan::PIPE; ++i)             // frames still in the pipeline: their download slots go back to the ctx
+        if (p->pipe_dl[i] >= 0 && p->pipe_dl[i] < sarx_ctx::DL_SLOTS) { sarx_memcpy_d2h_end(p->ctx, p->pipe_dl[i]); p->pipe_dl[i] = -1; }
     if (p->ctx->dl_stream) hipStreamSynchronize(p->ctx->dl_stream);
     for (int i = 0; i < sarx_plan::PIPE; ++i) { hipFree(p->pipe_in[i]); hipFree(p->pipe_out[i]); }
     delete p;

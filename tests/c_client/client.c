@@ -65,6 +65,26 @@ int main(int argc, char** argv) {
         sarx_host_free(ctx, pin);
     }
 
+    /* round 5: the host-array call as a pipeline - frame i+1 uploads while frame i focuses and downloads (sarx_csa_focus_host_begin /
+     * _end), once into page-locked results (asynchronous DMA) and once into ordinary memory (downloaded by _end); a third pending frame
+     * on one plan is refused with an error code */
+    {
+        void* pin[2] = {NULL, NULL};
+        float* pageable = malloc(n * 8);
+        int t0 = -1, t1 = -1, t2 = -1, same = 1;
+        if (sarx_host_alloc(ctx, n * 8, &pin[0]) || sarx_host_alloc(ctx, n * 8, &pin[1])) die(ctx, "host_alloc");
+        if (sarx_csa_focus_host_begin(plan, in, pin[0], &t0)) die(ctx, "host_begin 0");
+        if (sarx_csa_focus_host_begin(plan, in, pin[1], &t1)) die(ctx, "host_begin 1");
+        const int rc3 = sarx_csa_focus_host_begin(plan, in, pageable, &t2);
+        if (sarx_csa_focus_host_end(plan, t0)) die(ctx, "host_end 0");
+        if (sarx_csa_focus_host_begin(plan, in, pageable, &t2)) die(ctx, "host_begin 2");
+        if (sarx_csa_focus_host_end(plan, t1) || sarx_csa_focus_host_end(plan, t2)) die(ctx, "host_end");
+        same = memcmp(pin[0], out, n * 8) == 0 && memcmp(pin[1], out, n * 8) == 0 && memcmp(pageable, out, n * 8) == 0;
+        printf("pipeline_bit_identical %d third_pending_rc %d end_twice_rc %d\n", same, rc3, sarx_csa_focus_host_end(plan, t0));
+        sarx_host_free(ctx, pin[0]); sarx_host_free(ctx, pin[1]);
+        free(pageable);
+    }
+
     /* range axis and cross-range axis as the reference returns them */
     double* rax = malloc(sizeof(double) * n_rg);
     double* cax = malloc(sizeof(double) * n_az);

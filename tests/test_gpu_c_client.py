@@ -37,6 +37,8 @@ def test_c_client_focus_matches_oracle(tmp_path):
     assert m and int(m.group(1)) < 0 and len(m.group(2)) > 5
     m = re.search(r"lanes_bit_identical (\d) lane_out_of_range_rc (-?\d+)", r.stdout)      # two frames in flight, page-locked download
     assert m and m.group(1) == "1" and int(m.group(2)) < 0
+    m = re.search(r"pipeline_bit_identical (\d) third_pending_rc (-?\d+) end_twice_rc (-?\d+)", r.stdout)    # sarx_csa_focus_host_begin / _end
+    assert m and m.group(1) == "1" and int(m.group(2)) < 0 and int(m.group(3)) < 0
     m = re.search(r"range_axis (\S+) (\S+) cross_range (\S+) (\S+)", r.stdout)
     got = [float(x) for x in m.groups()]
     np.testing.assert_allclose(got, [rax[0], rax[-1], cax[0], cax[-1]], rtol=1e-9, atol=1e-6)
