@@ -620,7 +620,7 @@ def main():
     # HBM bytes per launch: PMC counters cannot be read inside this process; the figure is REPLAYED from the separate
     # rocprofv3 --pmc passes kept under profiles/ (tools/pmc_traffic.sh), and labelled as such
     def replay(kernel_substr):
-        for name in ("r04_pmc_range_kernels.json", "r03_pmc_range_kernels.json", "r02_pmc_range_kernels.json", "r01_pmc_traffic.json"):
+        for name in ("r05_pmc_range_kernels.json", "r04_pmc_range_kernels.json", "r03_pmc_range_kernels.json", "r02_pmc_range_kernels.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pmc = json.load(fh)
@@ -629,9 +629,10 @@ def main():
             except (OSError, StopIteration, KeyError, ValueError):
                 continue
         return None, None
-    traffic, traffic_src, traffic_p2, traffic_p2_src = None, None, None, None
+    traffic, traffic_src, traffic_p2, traffic_p2_src, traffic_alone, traffic_alone_src = None, None, None, None, None, None
     if n == 16384 and not a.unfused:
-        traffic, traffic_src = replay("range_fused")
+        traffic, traffic_src = replay("range_fused_wl_kernel")
+        traffic_alone, traffic_alone_src = replay("range_fused_wl_touch_kernel")
         traffic_p2, traffic_p2_src = replay("range_wp_kernel<2>")
 
     fused_wl = (not a.unfused) and n == 16384
@@ -641,7 +642,7 @@ def main():
     # code, not on the run); peak issue = one wave64 instruction per 2 cycles per SIMD-32, 4 SIMDs x CUs, at the 2.4 GHz maximum clock
     valu_insts, valu_src = None, None
     if fused_wl:
-        for name in ("r05_pmc_range_kernels.json", "r02_pmc_range_kernels.json"):
+        for name in ("r05_pmc_range_kernels.json", "r02_pmc_range_kernels.json"):       # (both kernel forms: 493.1 M / 493.9 M)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     kk = json.load(fh)["kernels"]
@@ -709,6 +710,9 @@ def main():
             # every launch - the kernel's own figure, kept beside the headline configuration's
             alone_ms = solo["range_launch_ms"]
             line["roofline_kernel_alone"] = roofline_block(alone_ms, "HIP events")
+            if fused_wl and traffic_alone:          # alone on the chip the launcher takes the touch-prefetch form of the kernel: its own counters
+                line["roofline_kernel_alone"].update(kernel="range_fused_wl_touch_kernel (the same launch with the next-line touch prefetch: chip to itself, in place)",
+                                                     traffic=traffic_alone, traffic_source=traffic_alone_src)
             line["roofline_kernel_alone"]["measured_in"] = (
                 f"the one_frame_in_flight leg of this run (lane 0 only, {solo['steps']} steps between barriers, grid sized for all CUs): HIP events "
                 "around every range launch, the kernel alone on the GPU; rocprofv3 summary of the same: profiles/r05_*_bench_inflight1_kernel_stats.csv "
@@ -718,7 +722,7 @@ def main():
         if collective:
             line["collective"] = {"transport": collective, "ranks": world, "rccl": rccl, "rccl_ranks": world if use_rccl else 0,
                                   "rank_devices": ranks_devices,
-                                  "stack": {"name": f"multilook {LOOKS}x{LOOKS} of |img|^2 (one {slot_bytes / 2**20:.0f} MiB slot per frame, emitted by the focus)",
+                                  "stack": {"name": f"multilook {LOOKS}x{LOOKS} of |img|^2 (one {slot_bytes / 2**20:.2f} MiB slot per frame, emitted by the focus)",
                                             "gather_bytes_per_rank_per_step": slot_bytes,
                                             "gather_s_per_step_at_one_xgmi_link": slot_bytes / (XGMI_LINK_GBS * 1e9),
                                             "link_bound_at_8_gpus": bool(slot_bytes / (XGMI_LINK_GBS * 1e9) > dt / K)}}

@@ -15,6 +15,7 @@
 #   py <name> <script> [args]    python3 <script> ...                                       -> <name>.log
 #   bin <name> <source.hip> [args]  hipcc -O3 the micro-benchmark if its .bin is missing, run it  -> <name>.log
 #   pmc <name> <counters> <script> [args]   one rocprofv3 --pmc pass (counters comma separated, kernel trace only) -> pmc_<name>/
+#   sh <name> <script.sh> [args]  bash <script.sh> args (the PMC scripts under tools/)               -> <name>.log
 #   env K=V ...                  exported for the steps that follow
 #   summary                      one line per bench_*.json written so far
 set -o pipefail
@@ -72,6 +73,12 @@ step_pmc() {   # counters in their own run: kernel trace only, never with --stat
   find "/tmp/pmc_$name" -name "*counter_collection.csv" -exec cp {} "$O/pmc_$name/" \; 2>/dev/null
   rm -rf "/tmp/pmc_$name"
   [ $rc -eq 0 ] || tail -15 "$O/pmc_${name}.log"
+  return $rc
+}
+step_sh() {      # a script of this repo (tools/*.sh) that does its own profiling calls: bash <script> args
+  local name=$1; shift
+  timeout -k 10 900 bash "$@" > "$O/$name.log" 2>&1; local rc=$?
+  tail -${GPU_CALL_TAIL:-20} "$O/$name.log"
   return $rc
 }
 step_summary() {
