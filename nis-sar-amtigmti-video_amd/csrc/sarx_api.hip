@@ -149,6 +149,10 @@ struct sarx_plan {
     sarx_radar_params p{};
     int az_s = 0;          // four-step split: n_az = (n_az/az_s) * az_s; az_s == n_az means single step
     int az_w = 32;         // azimuth tile width (range samples)
+    int az_w_alone = 0;    // > 0: width of the plain azimuth launches while the focus has the chip to itself (no CU share set): 64 columns =
+                           // 512-byte row segments at 16384^2, 1.57-1.58 against 1.62-1.66 ms per two-launch transform; with frames in flight
+                           // the 64 KiB tiles share CUs worse with the other lane's range launch (4.03-4.09 against 3.99-4.00 ms per frame),
+                           // at 8192^2 and below nothing changes (profiles/r05_p_az_tile_width.log)
     int look = 0;          // > 0: the last azimuth launch also writes row-wise |x|^2 partials and a finish launch turns them into look_slot
     float* look_slot = nullptr;   // caller's [n_az/look x n_rg/look] fp32 slot (device)
     float* look_part = nullptr;   // [n_az x n_rg/look], owned by the plan
@@ -654,6 +658,7 @@ static int sarx_csa_plan_create_impl(sarx_ctx* c, int n_az, int n_rg, const sarx
         }
     }
     if (const char* e = getenv("SARX_AZ_W")) { const int w = atoi(e); if ((w == 16 || w == 32 || w == 64) && n_rg % w == 0) p->az_w = w; }
+    else if (n_rg % 64 == 0 && (size_t)n_az * n_rg * sizeof(float2) >= ((size_t)1 << 31)) p->az_w_alone = 64;
 
     // migration factors, natural fftfreq order (sar_ati_dcpa_sim_csa.py:225,244-249,262)
     const double lam = prm->wavelength_m, Kr = prm->chirp_rate_hz_s, Vr = prm->platform_speed_mps, Rref = prm->range_ref_m;
@@ -883,10 +888,12 @@ static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, v
     a.in = (const float2*)in; a.out = (float2*)out;
     a.q0 = q0;
     a.nt = p->az_nt;
+    const bool alone = !(c->range_cus > 0 && c->range_cus < c->cus);
+    const int w_plain = (alone && p->az_w_alone) ? p->az_w_alone : p->az_w;      // the same columns' arithmetic either way: bit-identical images
     if (!step_b) {
         a.tw_r = c->tw_all + RA;
         a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
-        HIPCHK(c, launch_az_tile(RA, p->az_w, inv, AZ_EPI_TWIDDLE, a, nq, c->stream));
+        HIPCHK(c, launch_az_tile(RA, w_plain, inv, AZ_EPI_TWIDDLE, a, nq, c->stream));
     } else {
         a.tw_r = c->tw_all + S;
         a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
@@ -895,7 +902,7 @@ static int az_step(sarx_plan* p, bool inv, bool step_b, int S, const void* in, v
         const bool ati = inv && p->ati_s1;
         if (inv && !ati) a.max_out = reinterpret_cast<unsigned*>(p->max_slot);      // an armed ATI epilogue reads the slot (ati_thr): never reduce into it then
         if (ati) ati_args(p, a);
-        HIPCHK(c, launch_az_tile(S, ati ? p->ati_w : p->az_w, inv, inv ? (ati ? AZ_EPI_SCALE_ATI : look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, nq, c->stream));
+        HIPCHK(c, launch_az_tile(S, ati ? p->ati_w : look ? p->az_w : w_plain, inv, inv ? (ati ? AZ_EPI_SCALE_ATI : look ? AZ_EPI_SCALE_LOOK : AZ_EPI_SCALE) : AZ_EPI_PHI1, a, nq, c->stream));
     }
     return SARX_OK;
 }

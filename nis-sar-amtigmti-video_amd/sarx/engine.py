@@ -86,6 +86,13 @@ class PendingDownload:
             check(self.ctx.lib.sarx_memcpy_d2h_end(self.ctx.h, slot), self.ctx.h)
         return self.out
 
+    def __del__(self):                          # dropped without result(): the copy is waited for and its slot returned to the context
+        try:
+            if self.slot is not None and self.ctx.h is not None:
+                self.ctx.lib.sarx_memcpy_d2h_end(self.ctx.h, self.slot)
+        except Exception:
+            pass
+
 
 def download_block(ctx, ptr, ld_elems, row0, n_rows, col0, n_cols, dtype=np.complex64):
     """Rows [row0, row0+n_rows) x columns [col0, col0+n_cols) of a row-major device image with leading dimension

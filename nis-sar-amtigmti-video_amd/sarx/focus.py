@@ -93,6 +93,13 @@ class FocusFuture:
     def done(self):
         return self._ticket is None
 
+    def __del__(self):                          # dropped without result(): the frame leaves the plan's two-deep pipeline all the same
+        try:
+            if self._ticket is not None and self._plan.h is not None:
+                self._plan.focus_host_end(self._ticket)
+        except Exception:
+            pass
+
     def result(self):
         if self._ticket is not None:
             ticket, self._ticket = self._ticket, None

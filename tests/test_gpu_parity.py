@@ -776,6 +776,14 @@ def test_host_pipeline_bit_identical_and_bounded(sx, ctx):
     got = f2.result()[0]
     assert np.shares_memory(got, mine)
     np.testing.assert_array_equal(got, ref[2])
+    # futures dropped without result(): the pipeline and the download slots are given back (no "two frames in flight" afterwards)
+    for _ in range(3):
+        sx.sar_focus_csa_async(raws[4], *args, ctx=ctx)
+    import gc
+    gc.collect()
+    fa, fb = sx.sar_focus_csa_async(raws[0], *args, ctx=ctx), sx.sar_focus_csa_async(raws[1], *args, ctx=ctx)
+    np.testing.assert_array_equal(fa.result()[0], ref[0])
+    np.testing.assert_array_equal(fb.result()[0], ref[1])
     # the synchronous call on the same cached plan afterwards
     np.testing.assert_array_equal(sx.sar_focus_csa(raws[3], *args, ctx=ctx)[0], ref[3])
     # C ABI argument checking
