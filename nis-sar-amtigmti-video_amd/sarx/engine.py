@@ -51,11 +51,12 @@ class DeviceBuffer:
         check(self.ctx.lib.sarx_memcpy_h2d_unordered(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes), self.ctx.h)
         return self
 
-    def download_begin(self, dtype, shape):
+    def download_begin(self, dtype, shape, force=False):
         """Asynchronous download, ordered after everything enqueued so far on the current lane: returns a PendingDownload whose
-        result() waits for the copy and returns the array (page-locked, from the context's pool: reserve it with
-        Context.reserve_pinned so the first calls of a loop do not pay hipHostMalloc).  Overlaps later uploads and kernels."""
-        out = self.ctx.pinned_empty(shape, dtype, force=True)
+        result() waits for the copy and returns the array.  The copy is asynchronous when the context's pool hands out a page-locked
+        block for it - from a size's fourth request on, at once with force=True or after Context.reserve_pinned; otherwise (a one-shot
+        script, which should not pay hipHostMalloc for arrays it downloads once) it is the ordinary blocking copy into a NumPy array."""
+        out = self.ctx.pinned_empty(shape, dtype, force=force)
         if out.nbytes > self.nbytes:
             raise ValueError("download larger than buffer")
         return PendingDownload(self.ctx, out, self.ptr)

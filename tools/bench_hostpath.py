@@ -124,6 +124,18 @@ for i in range(8):
 fut.result()
 res["async_ms"] = [round(x, 2) for x in ivals]
 print(f"sar_focus_csa_async, begin(i+1) before result(i): {res['async_ms']} ms per frame", flush=True)
+# the whole two-channel processing section on host arrays (sar_ati_dcpa_sim_csa.py:402-419,447-449): two uploads, two focuses, five planes
+# back - channel 2 uploads while channel 1 focuses, slc1 downloads meanwhile, every plane's download in flight at once
+if n <= 8192:
+    raw_b = frames[1]
+    tc = []
+    for rep in range(7):
+        _, ms = timed(lambda: sarx.focus_ati_dpca(raw, raw_b, *args, pulse_shift=False))
+        tc.append(round(ms, 2))
+    res["two_channel_host_ms"] = tc
+    moved = 2 * raw.nbytes + 2 * raw.nbytes + 3 * raw.nbytes // 2
+    print(f"focus_ati_dpca {n}x{n} on host arrays (2 echoes up, slc1 + slc2 + 3 planes down = {moved / 2**30:.2f} GiB): {tc} ms per call "
+          f"(one direction after the other at 55 GB/s: {moved / 55e6:.0f} ms)", flush=True)
 res["steady_ms"] = min(res["calls_ms"][6:])
 res["floor_ms"] = round(res["upload_pageable_ms"] + res["focus_dev_ms"] + res["download_pinned_ms"], 2)
 print(json.dumps(res))
