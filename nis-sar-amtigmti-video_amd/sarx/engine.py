@@ -173,7 +173,7 @@ class Context:
     """sarx_ctx wrapper: one per GPU, owns a compute stream and a comm stream."""
 
     PINNED_MIN_BYTES = 64 << 20        # smaller results are plain NumPy arrays (the library copies them with one hipMemcpy anyway)
-    PINNED_FREE_PER_SIZE = 2           # free blocks kept per size; a caller that holds results alive gets fresh blocks
+    PINNED_FREE_PER_SIZE = 4           # free blocks kept per size (a two-channel call returns three planes of one size); a caller that holds more results alive gets fresh blocks
     PINNED_FROM_REQUEST = 4            # a size earns page-locked blocks from its fourth request on: hipHostMalloc costs 0.15 s per GiB,
                                        # up to 2.6 x the first touch of a pageable result, so a one-shot script (two images, three planes,
                                        # three intermediate maps of one size at most) never pays it; a frame loop pays it twice
