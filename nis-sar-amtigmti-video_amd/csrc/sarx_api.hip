@@ -1129,7 +1129,10 @@ int sarx_csa_focus_host_begin(sarx_plan* p, const void* phist_host, void* image_
     if (rc != SARX_OK) return rc;
     if (is_page_locked(image_host)) {
         int slot = -1;
-        if ((rc = sarx_memcpy_d2h_begin(c, image_host, p->pipe_out[s], img, &slot)) != SARX_OK) return rc;
+        if ((rc = sarx_memcpy_d2h_begin(c, image_host, p->pipe_out[s], img, &slot)) != SARX_OK) {
+            hipStreamSynchronize(c->stream);        // the focus is enqueued but the slot stays free: nothing may still touch its buffers
+            return rc;
+        }
         p->pipe_dl[s] = slot; p->pipe_host[s] = nullptr;
     } else {                       // a pageable result cannot be the target of an asynchronous DMA: _end downloads it (staged, blocking)
         p->pipe_dl[s] = sarx_ctx::DL_SLOTS; p->pipe_host[s] = image_host;

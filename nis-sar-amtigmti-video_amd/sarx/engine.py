@@ -478,12 +478,23 @@ class CsaPlan:
         if self.h is not None and self.ctx.h is not None:
             self.ctx.lib.sarx_csa_plan_destroy(self.h)
         self.h = None
+        buf, self._result_buf = getattr(self, "_result_buf", None), None
+        if buf is not None:
+            buf.release()
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    def result_buffer(self):
+        """A device image buffer owned by the plan and kept until it is closed: where the facade focuses a device-resident echo
+        before the blocking download (a fresh allocation per call costs its first touch - a download out of fresh device pages
+        ran 62 ms against 38 ms for 1.75 GiB - and hipFree waits for the device)."""
+        if getattr(self, "_result_buf", None) is None or self._result_buf.ptr is None:
+            self._result_buf = self.ctx.alloc(self.n_az * self.n_rg * 8)
+        return self._result_buf
 
     @property
     def rg_major(self):

@@ -98,10 +98,9 @@ def sar_focus_csa(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
             platform_speed_mps, range_ref_m, t_start_fast)
     plan = _get_plan(ctx, n_az, n_rg, args, flags)
     if on_device:
-        d_img = ctx.alloc(n_az * n_rg * 8)
+        d_img = plan.result_buffer()                 # the plan's own, reused from call to call (the download below is blocking)
         plan.focus_dev(a, d_img)
         img = d_img.download(np.complex64, (n_rg, n_az) if materialize_transpose else (n_az, n_rg))
-        d_img.release()
     else:
         dst = None
         if out is not None:
