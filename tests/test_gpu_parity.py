@@ -817,3 +817,32 @@ def test_two_channel_host_inputs_overlap_transfers_same_results(sx, ctx):
     o1 = orc.sar_focus_csa(r1, *args)[0]
     assert orc.rel_l2(host["slc1"], o1) < TOL
     d1.release(); d2.release()
+
+
+def test_host_pipeline_edges(sx, ctx):
+    """focus_stream / sar_focus_csa_async at the edges: an empty iterable, a single frame, the reference's complex128 arrays, a size
+    that is not a power of two (chirp-z route, reference fixture 96 x 80), frames of changing shape inside one stream - every result
+    equal to the synchronous call's and, for the fixture, to the reference's own output."""
+    g = load_golden("csa_96x80.npz")
+    args = tuple(float(v) for v in g["args"])
+    raw = g["phist"].astype(np.complex128)                             # the dtype the reference's arrays have
+    assert raw.shape == (96, 80)
+    assert list(sx.focus_stream(iter(()), *args, ctx=ctx)) == []
+    one = list(sx.focus_stream([raw], *args, ctx=ctx))
+    assert len(one) == 1
+    sync = sx.sar_focus_csa(raw, *args, ctx=ctx)
+    np.testing.assert_array_equal(one[0][0], sync[0])
+    np.testing.assert_array_equal(one[0][1], sync[1])
+    assert orc.rel_l2(one[0][0], g["img_T"]) < TOL                      # against the reference's own image
+    # frames of changing shape: each shape has its own cached plan and its own two-deep pipeline
+    raw_b, k = orc.point_scene(128, 64, seed=5, n_targets=3)
+    args_b = orc.focus_args(k)
+    ref_b = sx.sar_focus_csa(raw_b, *args_b, ctx=ctx)[0]
+    fa = sx.sar_focus_csa_async(raw, *args, ctx=ctx)
+    fb = sx.sar_focus_csa_async(raw_b, *args_b, ctx=ctx)
+    fc = sx.sar_focus_csa_async(raw.astype(np.complex64), *args, ctx=ctx)
+    np.testing.assert_array_equal(fb.result()[0], ref_b)
+    np.testing.assert_array_equal(fa.result()[0], sync[0])
+    assert orc.rel_l2(fc.result()[0], sync[0]) < 1e-6                  # complex64 input: the same rounding happens on the host instead
+    with pytest.raises(ValueError):
+        sx.sar_focus_csa_async(raw[0], *args, ctx=ctx)                 # not 2-D
