@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 205   /* 205: sarx_csa_plan_stamp_range (execution span of the fused range launch from in-kernel clock stamps), overlapped host transfers (sarx_memcpy_h2d_unordered, sarx_memcpy_d2h_begin / _end, sarx_csa_focus_host_begin / _end); 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
+#define SARX_VERSION 206   /* 206: sarx_rda_focus_host2 / _dev2 (the airborne script's eighth output, the azimuth-compressed map); 205: sarx_csa_plan_stamp_range (execution span of the fused range launch from in-kernel clock stamps), overlapped host transfers (sarx_memcpy_h2d_unordered, sarx_memcpy_d2h_begin / _end, sarx_csa_focus_host_begin / _end); 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -235,6 +235,16 @@ int sarx_rda_focus_host(sarx_rda_plan* plan, const void* phist_pulse_major_host,
  * is downloaded and nothing blocks. */
 int sarx_rda_focus_dev(sarx_rda_plan* plan, const void* d_phist_pulse_major, float* d_image_mag,
                        void* d_range_compressed, void* d_range_doppler, void* d_range_doppler_rcmc);
+/* The same two calls with the map sar_vehicle_sim.py:182-273 returns in addition (its eighth output, :268
+ * range_doppler_filtered = the range-Doppler map after RCMC and azimuth compression, Doppler order, [n_pulses x n_ranges]
+ * complex64; NULL = skip, and then these ARE the calls above).  sar_satellite_moving_sim.py:208-285 returns only the first
+ * three outputs: every optional pointer NULL. */
+int sarx_rda_focus_host2(sarx_rda_plan* plan, const void* phist_pulse_major_host, float* image_mag_host,
+                         void* range_compressed_host, void* range_doppler_host, void* range_doppler_rcmc_host,
+                         void* range_doppler_filtered_host);
+int sarx_rda_focus_dev2(sarx_rda_plan* plan, const void* d_phist_pulse_major, float* d_image_mag,
+                        void* d_range_compressed, void* d_range_doppler, void* d_range_doppler_rcmc,
+                        void* d_range_doppler_filtered);
 /* range_axis_centered[n_ranges] (:443-444), cross_range_m[n_pulses] (:442), doppler_freq[n_pulses] (:402-405) */
 int sarx_rda_axes(const sarx_rda_plan* plan, double* range_axis_centered, double* cross_range_m, double* doppler_freq);
 

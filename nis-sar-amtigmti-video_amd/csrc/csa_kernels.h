@@ -64,6 +64,9 @@ struct AzArgs {
     size_t io_ld;         // TWIDDLE_PADIN / CROPOUT: leading dimension and extents of the smaller array
     int io_rows, io_cols;
     int io_shift_in;      // TWIDDLE_PADIN: sequence element r is source row (r + io_shift_in) mod io_rows (fftshift bookkeeping)
+    float hamming_inv;    // TWIDDLE_PADIN, > 0: source row i is weighted 0.54 - 0.46 cos(2 pi i hamming_inv), hamming_inv = 1/(io_rows - 1):
+                          // the azimuth window of sar_focus_rda (:396) evaluated in the kernel - as a rowvec table it was a second
+                          // vector-memory instruction per row in a launch bound by their issue (0.316 against 0.214 ms at 32768 x 2048)
     int io_shift_out;     // CROPOUT*: sequence element r goes to destination row (r + io_shift_out) mod io_rows
     float* out_mag;       // CROPOUT_MAG: [io_rows x io_cols] fp32 magnitudes (leading dimension io_ld)
     bool nt;              // nontemporal image loads / stores (images too large to be re-read from cache before they are evicted)

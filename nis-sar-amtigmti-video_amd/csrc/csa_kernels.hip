@@ -22,8 +22,9 @@ template <int N> struct RangeCfg {
     static constexpr size_t LDS_BYTES = (size_t)ROWS * LDS_PER_ROW * sizeof(cf);
 };
 
+// (the 4096-point convolution needs 129 VGPRs left alone: one register over the fourth wave per SIMD that its four 34 KiB workgroups per CU could use)
 template <int N, int MODE>
-__global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeArgs a) {
+__global__ __launch_bounds__(RangeCfg<N>::THREADS, (N == 4096 && MODE == RG_CONV) ? 4 : 1) void range_pass_kernel(RangeArgs a) {
     using CFG = RangeCfg<N>;
     using PL = Plan<N>;
     constexpr int P = PL::P, T = PL::T;
@@ -37,10 +38,12 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
     if (!live) line = a.n_az - 1;                   // keep barriers uniform
     const int row = range_row(a, line);
     cf* my_lds = lds + r_in_wg * CFG::LDS_PER_ROW;
-    const cf* __restrict__ src = a.in + (size_t)row * N;
-    cf* __restrict__ dst = a.out + (size_t)row * N;
+    // RG_CONV: dense lines of conv_valid samples in, conv_out samples out (leading dimensions of their own); the transform
+    // length N only exists in registers and LDS
+    const cf* __restrict__ src = a.in + (size_t)row * (MODE == RG_CONV ? a.conv_in_ld : (size_t)N);
+    cf* __restrict__ dst = a.out + (size_t)row * (MODE == RG_CONV ? a.conv_out_ld : (size_t)N);
 
-    constexpr bool FWD_FIRST = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED);
+    constexpr bool FWD_FIRST = (MODE == RG_FFT || MODE == RG_FFT_PHI2 || MODE == RG_FUSED || MODE == RG_CONV);
     // the row's phase constants are requested FIRST: vmcnt retires in order, so they arrive with the line itself; next to their
     // use (mid-line) their latency was exposed once or twice per line
     double2 c2 = make_double2(0, 0), c3 = c2;
@@ -53,7 +56,14 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
 #pragma unroll
         for (int b = 0; b < P / R0; ++b)
 #pragma unroll
-            for (int r = 0; r < R0; ++r) v[b * R0 + r] = src[E::in_index(t, b, r)];
+            for (int r = 0; r < R0; ++r) {
+                if constexpr (MODE == RG_CONV) {      // zero padding up to N: neither stored nor read
+                    const int j = E::in_index(t, b, r);
+                    v[b * R0 + r] = j < a.conv_valid ? src[j] : make_float2(0.f, 0.f);
+                } else {
+                    v[b * R0 + r] = src[E::in_index(t, b, r)];
+                }
+            }
         stockham_run<N, 1, false, false>(v, t, 0, my_lds, a.tw);
         constexpr int RL = E::R_last;
         if constexpr (MODE == RG_FFT) {
@@ -75,6 +85,13 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
                     for (int r = 0; r < RL; ++r) dst[E::out_index(t, b, r)] = v[b * RL + r];
             }
             return;
+        } else if constexpr (MODE == RG_CONV) {
+            // spectrum of the matched filter at N points (natural order), one table for every line
+            const cf* __restrict__ mv = a.mulvec;
+#pragma unroll
+            for (int b = 0; b < P / RL; ++b)
+#pragma unroll
+                for (int r = 0; r < RL; ++r) v[b * RL + r] = cmul(v[b * RL + r], mv[E::out_index(t, b, r)]);
         } else {
             // output bin of register (b, r) is t + T*m with m = b + (P/RL)*r; bins >= N/2 are negative frequencies
             constexpr int B = P / RL;
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
     }
     // inverse half.  In the fused pass the registers already hold the first
     // inverse stage's inputs (plan reversed: remainder radix first).
-    constexpr bool REV = (MODE == RG_FUSED);
+    constexpr bool REV = (MODE == RG_FUSED || MODE == RG_CONV);
     using EI = Edge<N, REV>;
     if constexpr (!FWD_FIRST) {
         constexpr int R0 = EI::R_first;
@@ -113,6 +130,16 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS) void range_pass_kernel(RangeA
     if constexpr (MODE == RG_IFFT) {
 #pragma unroll
         for (int i = 0; i < P; ++i) v[i] = make_float2(v[i].x * s, v[i].y * s);
+    } else if constexpr (MODE == RG_CONV) {
+        // of the circular convolution only the 'same' window [conv_crop0, conv_crop0 + conv_out) is wanted (scipy convolve mode='same')
+        constexpr int B = P / RL;
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            const int reg = (m % B) * RL + m / B;
+            const int j = t + T * m - a.conv_crop0;
+            if (live && j >= 0 && j < a.conv_out) dst[j] = make_float2(v[reg].x * s, v[reg].y * s);
+        }
+        return;
     } else {
         FixPhase q = phi3_seed(t, T, c3, a.dt, a.t_start, a.t0);
         constexpr int B = P / RL;
@@ -157,6 +184,7 @@ template <int N> static hipError_t launch_range_mode(int mode, const RangeArgs& 
         case RG_FFT_PHI2: return launch_range<N, RG_FFT_PHI2>(a, st);
         case RG_IFFT_PHI3: return launch_range<N, RG_IFFT_PHI3>(a, st);
         case RG_FUSED: return launch_range<N, RG_FUSED>(a, st);
+        case RG_CONV: return launch_range<N, RG_CONV>(a, st);
     }
     return hipErrorInvalidValue;
 }
@@ -237,7 +265,10 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
                     size_t srow = rowi + (size_t)a.io_shift_in;             // circular row shift of the source (0 = none)
                     if (srow >= (size_t)a.io_rows) srow -= (size_t)a.io_rows;
                     x = a.in[srow * a.io_ld + col];
-                    if (a.rowvec) x = cmul(x, a.rowvec[rowi]);
+                    if (a.hamming_inv > 0.f) {
+                        const float w = fmaf(-0.46f, __builtin_amdgcn_cosf((float)srow * a.hamming_inv), 0.54f);
+                        x.x *= w; x.y *= w;
+                    } else if (a.rowvec) x = cmul(x, a.rowvec[rowi]);
                 }
             } else if constexpr (EPI == AZ_EPI_TWIDDLE_ROWSIN) {
                 x = rowi < (size_t)a.io_rows ? a.in[rowi * a.n_rg + col] : make_float2(0.f, 0.f);
@@ -390,6 +421,8 @@ template <int R, int W> static hipError_t launch_az_rw(bool inv, int epi, const 
             case AZ_EPI_ROWVEC: return launch_az_one<R, W, false, AZ_EPI_ROWVEC>(a, nq, st);
             case AZ_EPI_TWIDDLE_PADIN: return launch_az_one<R, W, false, AZ_EPI_TWIDDLE_PADIN>(a, nq, st);
             case AZ_EPI_TWIDDLE_ROWSIN: return launch_az_one<R, W, false, AZ_EPI_TWIDDLE_ROWSIN>(a, nq, st);
+            case AZ_EPI_CROPOUT:      // last step of a forward two-step transform (R >= 16) into a dense array, rows rotated (RDA)
+                if constexpr (R >= 16 && W == 32) return launch_az_one<R, W, false, AZ_EPI_CROPOUT>(a, nq, st); else return hipErrorInvalidValue;
         }
     } else {
         switch (epi) {

@@ -47,9 +47,11 @@ Rda* rda_create(int n_ranges, int n_pulses, const sarx_radar_params* prm, const 
 void rda_destroy(Rda* r);
 // mag_out: device buffer for the [n_pulses x n_ranges] magnitude (nullptr: the object's own, see rda_mag);
 // want_rc: also keep the RCMC map (rda_stage(r, 2)); the other two intermediates are pipeline buffers and always valid
-hipError_t rda_focus(Rda* r, const float2* d_in_pulse_major, hipStream_t st, float* mag_out = nullptr, bool want_rc = true);
+// want_ac: also keep the azimuth-compressed map (rda_stage(r, 3); sar_vehicle_sim.py:268 range_doppler_filtered)
+hipError_t rda_focus(Rda* r, const float2* d_in_pulse_major, hipStream_t st, float* mag_out = nullptr, bool want_rc = true,
+                     bool want_ac = false);
 const float* rda_mag(const Rda* r);                 // [n_pulses x n_ranges] = the reference's sar_image_mag.T
-const float2* rda_stage(const Rda* r, int which);   // 0 range-compressed, 1 range-Doppler, 2 after RCMC; [n_pulses x n_ranges]
+const float2* rda_stage(const Rda* r, int which);   // 0 range-compressed, 1 range-Doppler, 2 after RCMC, 3 after azimuth compression (want_ac); [n_pulses x n_ranges]
 void rda_axes(const Rda* r, double* range_centered, double* cross_range, double* doppler);
 uint64_t rda_bytes(const Rda* r);
 }  // namespace sarx

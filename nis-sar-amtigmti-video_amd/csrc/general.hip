@@ -389,6 +389,39 @@ static hipError_t cols_bluestein3(GeneralCsa* g, cf* x, bool inv, hipStream_t st
     return launch_az_tile(RA, 32, true, dst.mag ? AZ_EPI_CROPOUT_MAG : epi_last, a, S, st);
 }
 
+// Direct two-step column transform of a power-of-two length n > 128 with both ends fused: the first step reads the dense
+// array src (rows rotated by src.shift, times src.rowvec by sequence index) - or, src.p == nullptr, the work array x
+// itself, already in sequence order -, the last step writes the dense array dst (rows rotated by dst.shift, scaled) or its
+// magnitude.  Two launches, x is the only intermediate.
+static hipError_t cols_pow2_ends(GeneralCsa* g, cf* x, int n, bool inv, hipStream_t st, const ColsSrc& src, const ColsDst& dst,
+                                 float hamming_inv = 0.f) {       // > 0: Hamming weight by SOURCE row, computed in the first step (AzArgs)
+    const int ld = g->ldc;
+    int l2 = 0;
+    while ((1 << l2) < n) ++l2;
+    const int S = 1 << (l2 / 2), RA = n / S;
+    AzArgs a{};
+    a.n_rg = ld;
+    a.scale = 1.0f / (float)n;                           // four-step twiddle argument q m / n
+    a.tw_n = n <= 16384 ? g->tw_all + n : nullptr;
+    a.in = src.p ? src.p : x; a.out = x; a.tw_r = g->tw_all + RA;
+    a.in_q_stride = 1; a.in_m_stride = S; a.out_q_stride = 1; a.out_m_stride = S;
+    if (src.p) {
+        if (inv) return hipErrorInvalidValue;            // the inverse's copy-in form is not instantiated
+        a.io_ld = src.ld; a.io_rows = src.rows; a.io_cols = src.cols; a.rowvec = src.rowvec; a.io_shift_in = src.shift;
+        a.hamming_inv = hamming_inv;
+        GCK(launch_az_tile(RA, 32, false, AZ_EPI_TWIDDLE_PADIN, a, S, st));
+        a.hamming_inv = 0.f;
+    } else {
+        GCK(launch_az_tile(RA, 32, inv, AZ_EPI_TWIDDLE, a, S, st));
+    }
+    a.in = x; a.out = dst.p; a.tw_r = g->tw_all + S; a.rowvec = dst.rowvec;
+    a.in_q_stride = S; a.in_m_stride = 1; a.out_q_stride = 1; a.out_m_stride = RA;
+    a.io_ld = dst.ld; a.io_rows = dst.rows; a.io_cols = dst.cols; a.io_shift_in = 0; a.io_shift_out = dst.shift; a.out_mag = dst.mag;
+    a.scale = dst.scale;
+    if (dst.mag && !inv) return hipErrorInvalidValue;
+    return launch_az_tile(S, 32, inv, dst.mag ? AZ_EPI_CROPOUT_MAG : AZ_EPI_CROPOUT, a, RA, st);
+}
+
 // line transform in place on w [n_az x m_rg] (chirped and padded when the axis is not direct)
 static hipError_t rows_core(GeneralCsa* g, cf* w, bool inv, hipStream_t st) {
     const Axis& ax = g->rg;
@@ -565,6 +598,10 @@ struct RdaArgsDev {
     double k_ac;           // lambda / (2 Vr^2):  1/Ka = k_ac * r
     const double2* rowc;   // [n_p] {s_k = 1 - alpha_k, 1 / s_k} (rda_rcmc_azcomp_rows_kernel: no fp64 division per pixel)
     double inv_dr;         // (n_r - 1) / (r_axis[n_r - 1] - r_axis[0])
+    // rda_rcmc_azcomp*_kernel: Doppler row k goes to row (k + out_shift) mod n_p of `out` (leading dimension out_ld): the
+    // ifftshift in front of the inverse transform folded into this store (power-of-two direct route); 0 / n_r otherwise
+    int out_shift; size_t out_ld;
+    cf* ac_out;            // optional: the azimuth-compressed map in Doppler order, dense (sar_vehicle_sim.py:268 range_doppler_filtered)
 };
 // out[k][j] = lerp of in[k][.] at u = (r_j/(1-a_k) - r_0)/dr, zero outside the sampled span
 __global__ __launch_bounds__(256) void rda_rcmc_kernel(RdaArgsDev a) {
@@ -642,7 +679,11 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_kernel(RdaArgsDev a, cf* 
         }
         const size_t i = (size_t)k * a.n_r + j;
         if (rc_out) rc_out[i] = y;
-        a.out[i] = cmul(y, cis_rev(g * fd2));
+        const cf z = cmul(y, cis_rev(g * fd2));
+        if (a.ac_out) a.ac_out[i] = z;
+        int ko = k + a.out_shift;
+        if (ko >= a.n_p) ko -= a.n_p;
+        a.out[(size_t)ko * a.out_ld + j] = z;
     }
 }
 // The same pass with one Doppler row per blockIdx.y and four range samples per thread: everything that depends on the row
@@ -660,6 +701,8 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a,
     const double fd2 = a.fd[k] * a.fd[k];
     const cf* row = a.in + (size_t)k * a.n_r;
     const int last = a.n_r - 1;
+    int ko = k + a.out_shift;
+    if (ko >= a.n_p) ko -= a.n_p;
     // A thread's four pixels first request everything the estimated bracket jc = floor(u) needs (its two positions and its two
     // samples), then decide: written pixel by pixel with the two correction loops in between, a pixel was three dependent
     // loads deep and the four ran one after the other - the launch was bound by that latency chain, not by its traffic.
@@ -702,7 +745,9 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a,
         }
         const size_t i = (size_t)k * a.n_r + j;
         if (rc_out) rc_out[i] = y;
-        a.out[i] = cmul(y, cis_rev(-0.5 * a.k_ac * rj[m] * fd2));
+        const cf z = cmul(y, cis_rev(-0.5 * a.k_ac * rj[m] * fd2));
+        if (a.ac_out) a.ac_out[i] = z;
+        a.out[(size_t)ko * a.out_ld + j] = z;
     }
 }
 __global__ __launch_bounds__(256) void rda_mag_kernel(const cf* in, float* mag, size_t n) {
@@ -719,6 +764,11 @@ struct Rda {
     // length m_conv (range_mixed.hip, RG_CONV), pulse-axis transforms by the 32 x 225 prime-factor kernels (az_pfa7200.hip)
     int m_conv = 0; cf* hhat_conv = nullptr;   // filter spectrum at m_conv points, natural order
     bool pfa72 = false; float* winf = nullptr; // azimuth window as floats [n_p]
+    // power-of-two direct route (the airborne script's 2048 ranges x 32768 pulses, sar_vehicle_sim.py:41,86): range compression as
+    // ONE circular convolution of power-of-two length m_conv <= 16384 in registers / LDS (range_pass_kernel<m_conv, RG_CONV>),
+    // pulse-axis transforms as the two four-step launches with window, both fftshifts and the magnitude in their first / last step
+    bool az2 = false;
+    cf* ac = nullptr;                          // azimuth-compressed map (the airborne script's eighth output), allocated on first request
     double2* rowc = nullptr; double inv_dr = 0;  // per Doppler row {1 - alpha, 1 / (1 - alpha)} for the row-wise RCMC kernel
     int cus = 256;
     double *fd = nullptr, *r_axis = nullptr;
@@ -733,7 +783,7 @@ void rda_destroy(Rda* r) {
     if (!r) return;
     general_csa_destroy(r->g);
     hipFree(r->hhat); hipFree(r->win); hipFree(r->pre_f); hipFree(r->fd); hipFree(r->r_axis); hipFree(r->hhat_conv); hipFree(r->winf); hipFree(r->rowc);
-    hipFree(r->pc); hipFree(r->rd); hipFree(r->rc); hipFree(r->mag);
+    hipFree(r->pc); hipFree(r->rd); hipFree(r->rc); hipFree(r->mag); hipFree(r->ac);
     delete r;
 }
 
@@ -756,7 +806,13 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
         // convolution when the wrapped ends miss it: M >= full - c0 and M >= c0 + n_r
         const int c0 = (l_mf - 1) / 2, full = n_r + l_mf - 1, m_need = std::max(full - c0, c0 + n_r);
         if (direct && m_c > 16384 && range_conv_supported(19683) && m_need <= 19683 && n_r <= 19683) r->m_conv = 19683;
+        if (direct && !r->m_conv) {      // shortest power of two that holds the 'same' window; the line kernels go up to 16384
+            int mp = 16;
+            while (mp < m_need) mp <<= 1;
+            if (mp <= 16384) r->m_conv = mp;
+        }
         r->pfa72 = direct && az_pfa7200_supported(n_p);
+        r->az2 = direct && !r->pfa72 && is_pow2(n_p) && cols_two_step(n_p) && n_p <= 32768;
     }
     r->g = general_csa_create(n_p, n_r, prm, tw_all, err, false, r->cus);      // buffers and the azimuth axis only
     if (!r->g) { delete r; return nullptr; }
@@ -789,7 +845,7 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
     if (r->m_conv) {                 // the same taps at the circular length of the direct kernel
         std::vector<zd> hc(r->m_conv, zd(0, 0));
         for (int k = 0; k < l_mf; ++k) hc[k] = h[k];
-        host_dft_any(hc);
+        if (is_pow2(r->m_conv)) host_fft(hc); else host_dft_any(hc);
         if ((e = upload(hc, &r->hhat_conv)) != hipSuccess) return bail("upload filter", e);
     }
     host_fft(h);
@@ -804,7 +860,12 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
         if ((e = hipMalloc(&r->winf, n_p * sizeof(float))) != hipSuccess) return bail("hipMalloc window", e);
         if ((e = hipMemcpy(r->winf, wf.data(), n_p * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload window", e);
     }
-    if (!r->pfa72 && !r->g->az.direct && cols_two_step(r->g->az.m)) {
+    if (r->az2) {
+        // (the Hamming window over pulses, :396, is evaluated by the first launch itself: AzArgs::hamming_inv)
+        // pad columns of the work arrays (ldc > n_r) are transformed along with the rest and never copied out: keep them finite
+        if ((e = hipMemset(r->g->work_a, 0, r->g->work_elems * sizeof(cf))) != hipSuccess) return bail("hipMemset", e);
+        if ((e = hipMemset(r->g->work_b, 0, r->g->work_elems * sizeof(cf))) != hipSuccess) return bail("hipMemset", e);
+    } else if (!r->pfa72 && !r->g->az.direct && cols_two_step(r->g->az.m)) {
         // three-launch chirp-z along pulses: window and fftshift are folded into the copy-in; sequence element e is
         // source row (e + sh) mod n_p (the roll by n_p/2 of :396-399), so it carries chirp[e] * window[(e + sh) mod n_p]
         const int sh = (n_p - n_p / 2) % n_p;
@@ -848,9 +909,10 @@ Rda* rda_create(int n_r, int n_p, const sarx_radar_params* prm, const float2* tw
 }
 
 // d_in: [n_p x n_r] complex64 (the reference's phist transposed).  Results stay in the object's buffers.
-hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out, bool want_rc) {
+hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out, bool want_rc, bool want_ac) {
     GeneralCsa* g = r->g;
     if (!mag_out) mag_out = r->mag;
+    if (want_ac && !r->ac) GCK(hipMalloc(&r->ac, (size_t)r->n_p * r->n_r * sizeof(cf)));
     const int n_p = r->n_p, n_r = r->n_r, m = r->m_c;
     cf* w = g->work_a;
     // 1 range compression
@@ -859,7 +921,8 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out,
         RangeArgs ca{};
         ca.in = d_in; ca.out = r->pc; ca.n_az = n_p; ca.inv_n = 1.0f / (float)r->m_conv; ca.mulvec = r->hhat_conv; ca.mul_period = 1;
         ca.conv_valid = n_r; ca.conv_crop0 = (r->l_mf - 1) / 2; ca.conv_out = n_r; ca.conv_in_ld = (size_t)n_r; ca.conv_out_ld = (size_t)n_r;
-        GCK(launch_range_conv(r->m_conv, ca, r->cus, st));
+        if (is_pow2(r->m_conv)) { ca.tw = g->tw_all + r->m_conv; GCK(launch_range_pass(r->m_conv, RG_CONV, ca, st)); }
+        else GCK(launch_range_conv(r->m_conv, ca, r->cus, st));
     } else {
     // split lines (m > 16384): the zero padding is neither written nor read, and only the 'same' window is written back
     const int vin = m > 16384 ? n_r : 0, vout = m > 16384 ? (r->l_mf - 1) / 2 + n_r : 0;
@@ -871,7 +934,11 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out,
     // 2 window, fftshift . FFT . fftshift over pulses: roll by h = n_p/2 is source row (r - h) mod n
     const int h = n_p / 2, sh = (n_p - h) % n_p;
     const bool z3 = r->pre_f != nullptr;           // chirp-z along pulses in three launches, shifts / window / magnitude in its ends
-    if (r->pfa72) {                                // two prime-factor launches, window and both fftshifts in their row addresses
+    if (r->az2) {                                  // two four-step launches: window and fftshift while copying in, fftshift while copying out
+        const ColsSrc src{r->pc, (size_t)n_r, n_p, n_r, nullptr, sh};
+        const ColsDst dst{r->rd, (size_t)n_r, n_p, n_r, nullptr, 1.0f, (n_p - sh) % n_p, nullptr};
+        GCK(cols_pow2_ends(g, g->work_a, n_p, false, st, src, dst, 1.0f / (float)(n_p - 1)));
+    } else if (r->pfa72) {                         // two prime-factor launches, window and both fftshifts in their row addresses
         GCK(az_pfa7200_run(false, r->pc, (size_t)n_r, n_r, g->work_a, (size_t)g->ldc, r->rd, nullptr, (size_t)n_r, sh, sh, r->winf, 1.0f, st));
     } else if (z3) {
         const ColsSrc src{r->pc, (size_t)n_r, n_p, n_r, r->pre_f, sh};
@@ -886,6 +953,10 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out,
     a.k_rcmc = r->lam * r->lam / (8.0 * r->vr * r->vr);
     a.k_ac = r->lam / (2.0 * r->vr * r->vr);
     a.in = r->rd; a.out = g->data; a.rowc = r->rowc; a.inv_dr = r->inv_dr;
+    a.out_shift = 0; a.out_ld = (size_t)n_r; a.ac_out = want_ac ? r->ac : nullptr;
+    if (r->az2) {          // straight into the inverse transform's work array, in its sequence order (the ifftshift of :438)
+        a.out = g->work_b; a.out_ld = (size_t)g->ldc; a.out_shift = (n_p - h) % n_p;
+    }
     if (n_r > 1 && n_p <= 65535) {
         hipLaunchKernelGGL(rda_rcmc_azcomp_rows_kernel, dim3((n_r + 1023) / 1024, n_p), dim3(256), 0, st, a, want_rc ? r->rc : (cf*)nullptr);
     } else {
@@ -894,6 +965,11 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out,
     }
     GCK(hipGetLastError());
     // 5 ifftshift . IFFT . ifftshift: source row (r + h) mod n both ways; magnitude
+    if (r->az2) {
+        const ColsSrc src{nullptr, 0, 0, 0, nullptr, 0};
+        const ColsDst dst{nullptr, (size_t)n_r, n_p, n_r, nullptr, 1.0f / (float)n_p, (n_p - h) % n_p, mag_out};
+        return cols_pow2_ends(g, g->work_b, n_p, true, st, src, dst);
+    }
     if (r->pfa72)
         return az_pfa7200_run(true, g->data, (size_t)n_r, n_r, g->work_a, (size_t)g->ldc, nullptr, mag_out, (size_t)n_r, h, h, nullptr,
                               1.0f / (float)n_p, st);
@@ -908,7 +984,7 @@ hipError_t rda_focus(Rda* r, const float2* d_in, hipStream_t st, float* mag_out,
 }
 
 const float* rda_mag(const Rda* r) { return r->mag; }
-const float2* rda_stage(const Rda* r, int which) { return which == 0 ? r->pc : which == 1 ? r->rd : r->rc; }
+const float2* rda_stage(const Rda* r, int which) { return which == 0 ? r->pc : which == 1 ? r->rd : which == 2 ? r->rc : r->ac; }
 void rda_axes(const Rda* r, double* range_centered, double* cross_range, double* doppler) {
     double mean = 0;
     for (double v : r->h_r) mean += v;

@@ -1195,31 +1195,37 @@ int sarx_rda_plan_destroy(sarx_rda_plan* p) {
     delete p;
     return SARX_OK;
 }
-int sarx_rda_focus_host(sarx_rda_plan* p, const void* phist, float* mag, void* pc, void* rd, void* rc) {
+int sarx_rda_focus_host2(sarx_rda_plan* p, const void* phist, float* mag, void* pc, void* rd, void* rc, void* ac) {
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
     sarx_ctx* c = p->ctx;
     hipSetDevice(c->device);
     if (!phist || !mag) return fail(c, SARX_ERR_INVALID, "NULL host pointer");
     const size_t px = (size_t)p->n_r * p->n_p;
     HIPCHK(c, staged_copy(c, p->d_in, phist, px * sizeof(float2), true));
-    HIPCHK(c, rda_focus(p->r, p->d_in, c->stream, nullptr, rc != nullptr));
+    HIPCHK(c, rda_focus(p->r, p->d_in, c->stream, nullptr, rc != nullptr, ac != nullptr));
     HIPCHK(c, staged_copy(c, mag, rda_mag(p->r), px * sizeof(float), false));
-    void* outs[3] = {pc, rd, rc};
-    for (int i = 0; i < 3; ++i)
+    void* outs[4] = {pc, rd, rc, ac};
+    for (int i = 0; i < 4; ++i)
         if (outs[i]) HIPCHK(c, staged_copy(c, outs[i], rda_stage(p->r, i), px * sizeof(float2), false));
     return SARX_OK;
 }
-int sarx_rda_focus_dev(sarx_rda_plan* p, const void* d_phist, float* d_mag, void* d_pc, void* d_rd, void* d_rc) {
+int sarx_rda_focus_host(sarx_rda_plan* p, const void* phist, float* mag, void* pc, void* rd, void* rc) {
+    return sarx_rda_focus_host2(p, phist, mag, pc, rd, rc, nullptr);
+}
+int sarx_rda_focus_dev2(sarx_rda_plan* p, const void* d_phist, float* d_mag, void* d_pc, void* d_rd, void* d_rc, void* d_ac) {
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");
     sarx_ctx* c = p->ctx;
     hipSetDevice(c->device);
     if (!d_phist || !d_mag) return fail(c, SARX_ERR_INVALID, "NULL pointer");
     const size_t px = (size_t)p->n_r * p->n_p;
-    HIPCHK(c, rda_focus(p->r, (const float2*)d_phist, c->stream, d_mag, d_rc != nullptr));   // magnitude written in place by the last launch
-    void* outs[3] = {d_pc, d_rd, d_rc};
-    for (int i = 0; i < 3; ++i)
+    HIPCHK(c, rda_focus(p->r, (const float2*)d_phist, c->stream, d_mag, d_rc != nullptr, d_ac != nullptr));   // magnitude written in place by the last launch
+    void* outs[4] = {d_pc, d_rd, d_rc, d_ac};
+    for (int i = 0; i < 4; ++i)
         if (outs[i]) HIPCHK(c, hipMemcpyAsync(outs[i], rda_stage(p->r, i), px * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
     return SARX_OK;
+}
+int sarx_rda_focus_dev(sarx_rda_plan* p, const void* d_phist, float* d_mag, void* d_pc, void* d_rd, void* d_rc) {
+    return sarx_rda_focus_dev2(p, d_phist, d_mag, d_pc, d_rd, d_rc, nullptr);
 }
 int sarx_rda_axes(const sarx_rda_plan* p, double* range_centered, double* cross_range, double* doppler) {
     if (!p) return fail(nullptr, SARX_ERR_INVALID, "plan is NULL");

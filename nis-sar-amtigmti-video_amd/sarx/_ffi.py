@@ -97,6 +97,8 @@ SIGNATURES = {
     "sarx_rda_plan_destroy": (_i, [_vp]),
     "sarx_rda_focus_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sarx_rda_focus_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "sarx_rda_focus_host2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sarx_rda_focus_dev2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sarx_rda_axes": (_i, [_vp, _vp, _vp, _vp]),
     "sarx_ati_dpca_dev": (_i, [_vp, _vp, _vp, _sz, _d, _P(AtiOutputs), _P(_d), _P(_d)]),
     "sarx_ati_stats": (_i, [_vp, _P(_d), _P(_d)]),

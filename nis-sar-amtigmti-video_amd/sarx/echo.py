@@ -93,9 +93,10 @@ def run_physics_engine(targets, pos_sat, t_vec, *, BW=None, T_p=None, R0=None, C
     return _download(d_raw, (pos_sat.shape[0], num_samples)), t_start_fast, fs
 
 
-def run_moving_physics(targets, t_vec, pos_sat, vel_target, *, BW=None, T_p=None, R0=None, C=None, FC=None, ctx=None):
+def run_moving_physics(targets, t_vec, pos_sat, vel_target, *, BW=None, T_p=None, R0=None, C=None, FC=None, ctx=None,
+                       device=False):
     """Monostatic echo of targets moving at ``vel_target``; drop-in for sar_satellite_moving_sim.py:111-159.
-    returns (raw [len(t_vec) x 13200] complex64, t_start_fast, fs)"""
+    returns (raw [len(t_vec) x 13200] complex64, t_start_fast, fs); ``device=True``: raw stays on the GPU as a DeviceArray"""
     k = radar.reference_constants()
     BW, T_p, R0 = (BW or k["BW"]), (T_p or k["T_p"]), (R0 or k["R0"])
     C, FC = (C or k["C"]), (FC or k["FC"])
@@ -111,12 +112,15 @@ def run_moving_physics(targets, t_vec, pos_sat, vel_target, *, BW=None, T_p=None
     # P(t) = P0 + V t (:137), tau = 2 d / C, phase -4 pi FC d / C (:143-144): geometry kernel
     d_raw = synth_device(ctx, 0, t_pos, np.asarray(vel_target, dtype=np.float64), t_vec, pos_sat, None, amp, t_fast_abs, BW / T_p,
                          T_p, C, FC)
+    if device:
+        return DeviceArray(d_raw, (t_vec.size, num_samples)), t_start_fast, fs
     return _download(d_raw, (t_vec.size, num_samples)), t_start_fast, fs
 
 
-def run_custom_physics(targets, t_vec, pos, tuned_prp, t_p, fc, bw, *, R0=None, C=None, ctx=None):
+def run_custom_physics(targets, t_vec, pos, tuned_prp, t_p, fc, bw, *, R0=None, C=None, ctx=None, device=False):
     """The vehicle script's monostatic echo (2048 samples at 360 MHz); drop-in for sar_vehicle_sim.py:83-128
-    (``tuned_prp`` is accepted and unused, as in the reference; R0 and C are its module globals).  returns raw complex64"""
+    (``tuned_prp`` is accepted and unused, as in the reference; R0 and C are its module globals).  returns raw complex64;
+    ``device=True``: raw stays on the GPU as a DeviceArray"""
     k = radar.reference_constants()
     R0, C = (R0 or k["R0"]), (C or k["C"])
     ctx = ctx or default_context()
@@ -127,6 +131,8 @@ def run_custom_physics(targets, t_vec, pos, tuned_prp, t_p, fc, bw, *, R0=None, 
     amp = np.sqrt(np.array([t["rcs"] for t in targets], dtype=np.float64))
     pos = np.asarray(pos, dtype=np.float64)[: len(t_vec)]
     d_raw = synth_device(ctx, 0, t_pos, None, None, pos, None, amp, t_fast_abs, bw / t_p, t_p, C, fc)
+    if device:
+        return DeviceArray(d_raw, (pos.shape[0], num_samples))
     return _download(d_raw, (pos.shape[0], num_samples))
 
 

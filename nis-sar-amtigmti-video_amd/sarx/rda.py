@@ -48,8 +48,11 @@ def _plan(ctx, n_r, n_p, prm):
     return plan
 
 
+VARIANTS = ("satellite", "moving", "vehicle")
+
+
 def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
-                  platform_speed_mps, range_grp_m, *, ctx=None, intermediates=True, device_output=False):
+                  platform_speed_mps, range_grp_m, *, ctx=None, intermediates=True, device_output=False, variant="satellite"):
     """phist: [num_ranges x num_pulses] complex (the scripts pass ``raw_data.T``); a NumPy array, or ``d.T`` of the
     [pulses x ranges] DeviceArray an echo generator returned with ``device=True`` (nothing is uploaded then).
 
@@ -58,7 +61,17 @@ def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     Images are float32 / complex64.  ``intermediates=False`` skips downloading the three complex maps
     (they come back as None).  ``device_output=True`` (device input only) leaves the images on the GPU: the tuple then
     holds DeviceBuffers ([pulses x ranges] row-major: float32 magnitude, complex64 maps) and nothing is downloaded.
+
+    ``variant`` selects which of the three pasted copies' return tuple comes back (the arithmetic is the same in all three):
+    "satellite" the 7-tuple above; "moving" sar_satellite_moving_sim.py:208-285's 3-tuple (sar_image_mag.T,
+    range_axis_centered, cross_range_m) - no intermediate is stored or downloaded; "vehicle" sar_vehicle_sim.py:182-273's
+    8-tuple, the 7-tuple with range_doppler_filtered (the map after azimuth compression, :268) in front of doppler_freq.
     """
+    if variant not in VARIANTS:
+        raise ValueError(f"variant must be one of {VARIANTS}")
+    if variant == "moving":
+        intermediates = False
+    n_maps = 4 if variant == "vehicle" else 3
     on_device = isinstance(phist, DeviceArray)
     if on_device:
         if not phist.transposed:
@@ -84,14 +97,17 @@ def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
             d_mag = ctx.alloc(n_p * n_r * 4)
             bufs.append(d_mag)
             d_st = []
-            for _ in range(3):
+            for _ in range(n_maps):
                 d_st.append(ctx.alloc(n_p * n_r * 8) if intermediates else None)
                 bufs.append(d_st[-1])
-            check(lib.sarx_rda_focus_dev(plan.h, phist.ptr, d_mag.ptr, *[b.ptr if b is not None else None for b in d_st]), ctx.h)
+            ptrs = [b.ptr if b is not None else None for b in d_st] + [None] * (4 - n_maps)
+            check(lib.sarx_rda_focus_dev2(plan.h, phist.ptr, d_mag.ptr, *ptrs), ctx.h)
             if device_output:
                 r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
                 check(lib.sarx_rda_axes(plan.h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
                 handed_over = True
+                if variant == "moving":
+                    return (d_mag, r_ax, c_ax)
                 return (d_mag, r_ax, c_ax, *d_st, fd)
             mag = d_mag.download(np.float32, (n_p, n_r))
             stages = [b.download(np.complex64, (n_p, n_r)) if b is not None else None for b in d_st]
@@ -104,10 +120,12 @@ def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
         if device_output:
             raise ValueError("device_output needs a device input (DeviceArray .T)")
         mag = ctx.pinned_empty((n_p, n_r), np.float32)             # large results: page-locked pool (one DMA, no first touch)
-        stages = [ctx.pinned_empty((n_p, n_r), np.complex64) if intermediates else None for _ in range(3)]
-        ptr = [s.ctypes.data if s is not None else None for s in stages]
-        check(lib.sarx_rda_focus_host(plan.h, x.ctypes.data, mag.ctypes.data, ptr[0], ptr[1], ptr[2]), ctx.h)
+        stages = [ctx.pinned_empty((n_p, n_r), np.complex64) if intermediates else None for _ in range(n_maps)]
+        ptr = [s.ctypes.data if s is not None else None for s in stages] + [None] * (4 - n_maps)
+        check(lib.sarx_rda_focus_host2(plan.h, x.ctypes.data, mag.ctypes.data, *ptr), ctx.h)
     r_ax, c_ax, fd = np.empty(n_r), np.empty(n_p), np.empty(n_p)
     check(lib.sarx_rda_axes(plan.h, r_ax.ctypes.data, c_ax.ctypes.data, fd.ctypes.data), ctx.h)
-    pc, rd, rc = (s.T if s is not None else None for s in stages)
-    return mag, r_ax, c_ax, pc, rd, rc, fd
+    if variant == "moving":
+        return mag, r_ax, c_ax
+    maps = tuple(s.T if s is not None else None for s in stages)
+    return (mag, r_ax, c_ax, *maps, fd)

@@ -16,6 +16,8 @@ values; reference outputs are complex128):
   ati_128x128.npz          two-channel scene -> slc1, slc2 + the literal
                            expressions of :414-419,447-449 and viewer :249-250
   rda_<nr>x<np>.npz        sar_focus_rda             (sar_satellite_sim.py:356-448), all 7 outputs
+  rda_moving_<nr>x<np>.npz the copy in sar_satellite_moving_sim.py:208-285, its 3 outputs
+  rda_vehicle_<nr>x<np>.npz the copy in sar_vehicle_sim.py:182-273, its 8 outputs (range_doppler_filtered among them)
   destroyer.npz            generate_destroyer        (vehicle_targets.py:102-141)
   echo_mono.npz            run_physics_engine        (sar_satellite_sim.py:211-305)
   echo_bistatic.npz        run_bistatic_physics_gpu  (sar_ati_dcpa_sim_csa.py:106-181)
@@ -233,5 +235,36 @@ def make_tdbp():
               f"{np.abs(out['stdbp']).max():.4g}")
 
 
+def make_rda_variants():
+    """The two other pasted copies of sar_focus_rda, each run as it stands in its own script.  256 pulses: the size class
+    of the airborne script's 32768 (power of two, two-step pulse-axis transforms)."""
+    from scipy.interpolate import interp1d
+    from scipy.signal import convolve
+    from scipy.signal.windows import hamming
+    from oracle import rda_oracle as rda
+    env = {"np": np, "convolve": convolve, "hamming": hamming, "interp1d": interp1d}
+    ref_mov = extract("sar_satellite_moving_sim.py", "sar_focus_rda", dict(env))
+    ref_veh = extract("sar_vehicle_sim.py", "sar_focus_rda", dict(env))
+    nr, npul = 144, 80
+    phist, args = rda.rda_scene(nr, npul, seed=41)
+    o = quiet(ref_mov, phist.astype(np.complex128), *args)
+    assert len(o) == 3
+    np.savez_compressed(os.path.join(OUT, f"rda_moving_{nr}x{npul}.npz"), phist=phist, args=np.array(args, dtype=np.float64),
+                        image_mag_T=o[0], range_axis_centered=o[1], cross_range_m=o[2])
+    print(f"rda_moving_{nr}x{npul}: peak/mean {o[0].max() / o[0].mean():.1f}")
+    nr, npul = 96, 256
+    phist, args = rda.rda_scene(nr, npul, seed=42)
+    o = quiet(ref_veh, phist.astype(np.complex128), *args)
+    assert len(o) == 8
+    np.savez_compressed(os.path.join(OUT, f"rda_vehicle_{nr}x{npul}.npz"), phist=phist, args=np.array(args, dtype=np.float64),
+                        image_mag_T=o[0], range_axis_centered=o[1], cross_range_m=o[2], phist_compressed=o[3],
+                        range_doppler=o[4], range_doppler_rcmc=o[5], range_doppler_filtered=o[6], doppler_freq=o[7])
+    print(f"rda_vehicle_{nr}x{npul}: peak/mean {o[0].max() / o[0].mean():.1f}")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rda_variants":      # only these two files (the others are unchanged)
+        make_rda_variants()
+    else:
+        main()
+        make_rda_variants()

@@ -42,8 +42,10 @@ def conv_same(x, h):
 
 
 def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec, sample_rate_hz, prf_hz,
-                  platform_speed_mps, range_grp_m):
-    """phist: [num_ranges x num_pulses].  Returns the reference's 7-tuple (:447-448)."""
+                  platform_speed_mps, range_grp_m, variant="satellite"):
+    """phist: [num_ranges x num_pulses].  Returns the reference's 7-tuple (:447-448); variant="moving": the 3-tuple of
+    sar_satellite_moving_sim.py:208-285; variant="vehicle": the 8-tuple of sar_vehicle_sim.py:182-273 (range_doppler_filtered,
+    :268, in front of doppler_freq)."""
     phist = np.asarray(phist, dtype=np.complex128)
     c = C_LIGHT
     n_r, n_p = phist.shape
@@ -76,6 +78,10 @@ def sar_focus_rda(phist, center_wavelength_m, pulse_width_sec, chirp_rate_hzpsec
     filt = rcmc * np.exp(-1j * np.pi * ((1.0 / ka)[:, None] * fd[None, :] ** 2))
     # 5 image (:438-446)
     img = np.fft.ifftshift(np.fft.ifft(np.fft.ifftshift(filt, axes=1), axis=1), axes=1)
+    if variant == "moving":
+        return (np.abs(img).T, r_axis - np.mean(r_axis), vr * slow)
+    if variant == "vehicle":
+        return (np.abs(img).T, r_axis - np.mean(r_axis), vr * slow, pc, rd, rcmc, filt, fd)
     return (np.abs(img).T, r_axis - np.mean(r_axis), vr * slow, pc, rd, rcmc, fd)
 
 

@@ -105,6 +105,8 @@ static void argument_checking() {
     CHECK(sarx_rda_plan_destroy(nullptr) == SARX_OK);
     CHECK(sarx_rda_focus_host(nullptr, buf, &f, nullptr, nullptr, nullptr) != SARX_OK);
     CHECK(sarx_rda_focus_dev(nullptr, buf, &f, nullptr, nullptr, nullptr) != SARX_OK);
+    CHECK(sarx_rda_focus_host2(nullptr, buf, &f, nullptr, nullptr, nullptr, nullptr) != SARX_OK);
+    CHECK(sarx_rda_focus_dev2(nullptr, buf, &f, nullptr, nullptr, nullptr, nullptr) != SARX_OK);
     CHECK(sarx_rda_axes(nullptr, d, d, d) != SARX_OK);
     CHECK(sarx_ati_dpca_dev(nullptr, buf, buf, 4, 0.0, &outs, d, d) != SARX_OK);
     CHECK(sarx_ati_dpca_masked_dev(nullptr, buf, buf, 4, 0.0, &f, 0.05f, &outs) != SARX_OK);

@@ -29,7 +29,7 @@ def test_library_exports_every_symbol():
     lib = _ffi.load()
     for s in _header_symbols():
         assert hasattr(lib, s), s
-    assert lib.sarx_version() == 205
+    assert lib.sarx_version() == 206
 
 
 def test_struct_layouts():

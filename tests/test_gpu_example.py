@@ -49,6 +49,46 @@ def test_satellite_rda_example_schema(tmp_path):
     assert img.max() > 5 * np.median(img)
 
 
+def test_vehicle_rda_example_schema(tmp_path):
+    """examples/sar_vehicle_rda_gpu.py: the .npz keys and shapes of sar_vehicle_sim.py:291-307 (rd_az_comp = the eighth output of
+    that script's sar_focus_rda); 4096 pulses of the airborne geometry; the destroyer focuses."""
+    out = tmp_path / "sar_simulation_data.npz"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "sar_vehicle_rda_gpu.py"), "--pulses", "4096",
+                        "--out", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with np.load(out, allow_pickle=False) as z:
+        assert set(z.files) == {"raw_phist", "range_comp", "rd_map", "rd_rcmc", "rd_az_comp", "final_image", "range_axis",
+                                "cross_range", "doppler_axis", "platform_alt", "platform_vel", "look_ang", "inc_ang", "r0", "prf"}
+        img = z["final_image"]
+        for key in ("raw_phist", "range_comp", "rd_map", "rd_rcmc", "rd_az_comp"):
+            assert z[key].shape == (2048, 4096), key                 # [ranges x pulses], as the script saves them
+        assert img.shape == (4096, 2048) and z["range_axis"].shape == (2048,) and z["cross_range"].shape == (4096,)
+        assert float(z["prf"]) == 2000.0 and float(z["platform_vel"]) == 150.0
+        filt = z["rd_az_comp"]
+    assert np.isfinite(img).all() and np.isfinite(filt).all()
+    assert img.max() > 5 * np.median(img)
+
+
+def test_moving_ship_example_schema(tmp_path):
+    """examples/sar_satellite_moving_gpu.py: one .npz per scenario with the keys of sar_satellite_moving_sim.py:337-353; the moving
+    ship's image differs from the stationary one (azimuth displacement / smear of a radial mover)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "sar_satellite_moving_gpu.py"), "--pulses", "1024",
+                        "--outdir", str(tmp_path), "--scenarios", "stationary,moving_0deg"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    imgs = {}
+    for tag, speed in (("stationary", 0.0), ("0deg", 15.0)):
+        with np.load(tmp_path / f"sar_satellite_moving_scen_{tag}.npz", allow_pickle=False) as z:
+            assert set(z.files) == {"final_image", "range_axis", "cross_range", "orbit_alt", "orbit_vel", "look_ang", "inc_ang",
+                                    "r0", "v_eff", "prf", "scen_name", "ship_speed", "ship_heading", "ship_vel"}
+            assert z["final_image"].shape == (1024, 13200) and z["range_axis"].shape == (13200,) and z["cross_range"].shape == (1024,)
+            assert float(z["ship_speed"]) == speed and z["ship_vel"].shape == (3,)
+            imgs[tag] = z["final_image"]
+    assert not (tmp_path / "sar_satellite_moving_scen_45deg.npz").exists()
+    for im in imgs.values():
+        assert np.isfinite(im).all() and im.max() > 5 * np.median(im)
+    assert np.abs(imgs["stationary"] - imgs["0deg"]).max() > 0.1 * imgs["stationary"].max()
+
+
 def test_batch_tdbp_example(tmp_path):
     """examples/sar_batch_gpu.py at a reduced CPI: frame stacks for both algorithms; focusing at the target's
     velocity (mBP) gives a sharper ship than the static focus (StdBP) (sar_batch_sim.py:283-286)."""

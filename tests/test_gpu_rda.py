@@ -38,6 +38,77 @@ def test_rda_golden(name):
     _check(out, ref)
 
 
+def test_rda_the_other_two_copies_golden():
+    """variant="moving": sar_satellite_moving_sim.py:208-285's three outputs; variant="vehicle": sar_vehicle_sim.py:182-273's
+    eight, range_doppler_filtered (:268) among them - against fixtures each script's own copy wrote.  The vehicle fixture
+    has 256 pulses: the power-of-two direct route (one convolution launch, two-step pulse-axis transforms with the window,
+    the fftshifts and the magnitude in their ends: six launches)."""
+    import sarx
+    g = np.load(os.path.join(GOLD, "rda_moving_144x80.npz"))
+    out = sarx.sar_focus_rda(g["phist"], *[float(v) for v in g["args"]], variant="moving")
+    assert len(out) == 3
+    assert rel_l2(out[0], g["image_mag_T"]) < TOL
+    np.testing.assert_allclose(out[1], g["range_axis_centered"], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(out[2], g["cross_range_m"], rtol=1e-9, atol=1e-9)
+    g = np.load(os.path.join(GOLD, "rda_vehicle_96x256.npz"))
+    out = sarx.sar_focus_rda(g["phist"], *[float(v) for v in g["args"]], variant="vehicle")
+    assert len(out) == 8
+    _check(out[:6] + (out[7],), (g["image_mag_T"], g["range_axis_centered"], g["cross_range_m"], g["phist_compressed"],
+                                  g["range_doppler"], g["range_doppler_rcmc"], g["doppler_freq"]))
+    assert rel_l2(out[6], g["range_doppler_filtered"]) < TOL, "azimuth compression"
+    with pytest.raises(ValueError):
+        sarx.sar_focus_rda(g["phist"], *[float(v) for v in g["args"]], variant="airship")
+
+
+@pytest.mark.parametrize("n_r,n_p", [(1024, 512), (333, 256), (96, 4096)])
+def test_rda_power_of_two_direct_route_equals_padded_route(n_r, n_p, monkeypatch):
+    """SARX_RDA_DIRECT=0 keeps the route of rounds 2-4 (padded work arrays, fourteen launches) for A/B: every output of the
+    six-launch route against it, the azimuth-compressed map included; n_r = 333 has pad columns in the work arrays."""
+    import sarx
+    phist, args = rda.rda_scene(n_r, n_p, seed=5 * n_r + n_p)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SARX_RDA_DIRECT", mode)
+        outs[mode] = sarx.sar_focus_rda(phist, *args, variant="vehicle")
+    for i, what in ((0, "image"), (3, "range compression"), (4, "range-Doppler map"), (5, "RCMC"), (6, "azimuth compression")):
+        assert np.isfinite(outs["1"][i]).all()
+        assert rel_l2(outs["1"][i], outs["0"][i]) < 2e-5, what
+    ref = rda.sar_focus_rda(phist, *args, variant="vehicle")
+    assert rel_l2(outs["1"][0], ref[0]) < TOL and rel_l2(outs["1"][6], ref[6]) < TOL
+
+
+def test_rda_airborne_script_size():
+    """sar_vehicle_sim.py's own size and radar (:21-41,86-87,166-168,283-287): 2048 range samples x 32768 pulses, 10 GHz,
+    300 MHz over 1 us (361 taps), 360 MHz sampling, 2 kHz PRF, 150 m/s.  Point targets + noise, device-resident; the whole
+    image and every map against the oracle's complex128 run on the downloaded pulses."""
+    import sarx
+    n_r, n_p = 2048, 32768
+    c = 299792458.0
+    args = (c / 10e9, 1.0e-6, 300e6 / 1.0e-6, 360e6, 2000.0, 150.0, 20000.0 / np.cos(np.radians(45.0)))
+    r = np.random.default_rng(77)
+    raw = (0.05 * (r.standard_normal((n_p, n_r), dtype=np.float32) + 1j * r.standard_normal((n_p, n_r), dtype=np.float32))).astype(np.complex64)
+    # three point scatterers: chirp echoes with a quadratic range history over the aperture (what run_custom_physics writes, :83-128)
+    t_slow = (np.arange(n_p) - n_p / 2) / args[4]
+    fast = (np.arange(n_r) - n_r / 2) / args[3]
+    for (dx, dy, amp) in ((0.0, 0.0, 1.0), (40.0, -60.0, 0.7), (-25.0, 90.0, 0.5)):
+        rng_t = np.sqrt((args[6] + dx) ** 2 + (args[5] * t_slow - dy) ** 2)
+        tau = 2 * (rng_t - args[6]) / c
+        for i0 in range(0, n_p, 4096):
+            tl = fast[None, :] - tau[i0:i0 + 4096, None]
+            m = np.abs(tl) <= args[1] / 2
+            ph = -4 * np.pi * rng_t[i0:i0 + 4096, None] / args[0] + np.pi * args[2] * tl ** 2
+            raw[i0:i0 + 4096] += (amp * np.exp(1j * ph) * m).astype(np.complex64)
+    ctx = sarx.default_context()
+    d = sarx.DeviceArray(ctx.to_device(raw), raw.shape)
+    out = sarx.sar_focus_rda(d.T, *args, variant="vehicle")
+    d.release()
+    ref = rda.sar_focus_rda(raw.T, *args, variant="vehicle")
+    for i, what in ((0, "image"), (3, "range compression"), (4, "range-Doppler map"), (5, "RCMC"), (6, "azimuth compression")):
+        assert rel_l2(out[i], ref[i]) < TOL, what
+    assert out[0].max() > 20 * out[0].mean()          # the scatterers focus
+    np.testing.assert_allclose(out[7], ref[7], rtol=1e-12, atol=1e-9)
+
+
 @pytest.mark.parametrize("n_r,n_p", [(1024, 512), (1500, 700), (4096, 2048)])
 def test_rda_oracle(n_r, n_p):
     import sarx

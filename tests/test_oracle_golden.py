@@ -138,6 +138,25 @@ def test_rda_oracle_matches_reference(tag):
     np.testing.assert_allclose(o[6], g["doppler_freq"], rtol=1e-14, atol=1e-12)
 
 
+def test_rda_oracle_matches_the_other_two_copies():
+    """sar_focus_rda as pasted into sar_satellite_moving_sim.py:208-285 (three outputs) and sar_vehicle_sim.py:182-273
+    (eight outputs, range_doppler_filtered :268 among them): fixtures written by each script's own copy."""
+    from oracle import rda_oracle as rda
+    g = load_golden("rda_moving_144x80.npz")
+    o = rda.sar_focus_rda(g["phist"], *g["args"], variant="moving")
+    assert len(o) == 3 and o[0].shape == g["image_mag_T"].shape
+    assert orc.rel_l2(o[0], g["image_mag_T"]) < 1e-11
+    np.testing.assert_allclose(o[1], g["range_axis_centered"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(o[2], g["cross_range_m"], rtol=1e-13, atol=1e-9)
+    g = load_golden("rda_vehicle_96x256.npz")
+    o = rda.sar_focus_rda(g["phist"], *g["args"], variant="vehicle")
+    assert len(o) == 8
+    for i, key in ((0, "image_mag_T"), (3, "phist_compressed"), (4, "range_doppler"), (5, "range_doppler_rcmc"),
+                   (6, "range_doppler_filtered")):
+        assert orc.rel_l2(o[i], g[key]) < 1e-11, key
+    np.testing.assert_allclose(o[7], g["doppler_freq"], rtol=1e-14, atol=1e-12)
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_spotlight_echo_oracle_matches_reference(tag):
     """run_physics_spotlight + calculate_raw_snr_db (sar_batch_sim.py:85-169, :54-64); 2e8 rad carrier phase in fp64."""
