@@ -260,15 +260,13 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             const size_t rowi = in_base + (size_t)mi * a.in_m_stride;
             cf x;
             if constexpr (EPI == AZ_EPI_TWIDDLE_PADIN) {   // copy-in, zero padding and pre-chirp of general.hip fused into the first step
+                // Only the load sits under the bounds test; the weights are applied below, once every load of the tile has been issued.  With the multiply inside this branch each of a thread's 16 loads was waited for before the next was
+                // issued (0.306 against 0.211 ms for the same tiles without the branch, 32768 x 2048: profiles/r05_bc_*).
                 x = make_float2(0.f, 0.f);
                 if (rowi < (size_t)a.io_rows && col < a.io_cols) {
                     size_t srow = rowi + (size_t)a.io_shift_in;             // circular row shift of the source (0 = none)
                     if (srow >= (size_t)a.io_rows) srow -= (size_t)a.io_rows;
                     x = a.in[srow * a.io_ld + col];
-                    if (a.hamming_inv > 0.f) {
-                        const float w = fmaf(-0.46f, __builtin_amdgcn_cosf((float)srow * a.hamming_inv), 0.54f);
-                        x.x *= w; x.y *= w;
-                    } else if (a.rowvec) x = cmul(x, a.rowvec[rowi]);
                 }
             } else if constexpr (EPI == AZ_EPI_TWIDDLE_ROWSIN) {
                 x = rowi < (size_t)a.io_rows ? a.in[rowi * a.n_rg + col] : make_float2(0.f, 0.f);
@@ -283,6 +281,26 @@ __global__ __launch_bounds__((AzCfg<R, W>::THREADS)) void az_tile_kernel(AzArgs 
             }
             v[b * R0 + r] = x;
         }
+    if constexpr (EPI == AZ_EPI_TWIDDLE_PADIN) {       // the copy-in's weights (see above)
+        if (a.hamming_inv > 0.f || a.rowvec) {
+#pragma unroll
+            for (int b = 0; b < P / R0; ++b)
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    const size_t rowi = in_base + (size_t)E::in_index(t, b, r) * a.in_m_stride;
+                    if (rowi >= (size_t)a.io_rows) continue;                // padding rows: zeros, and rowvec has io_rows entries
+                    cf& x = v[b * R0 + r];
+                    if (a.hamming_inv > 0.f) {                              // weight of the SOURCE row
+                        size_t srow = rowi + (size_t)a.io_shift_in;
+                        if (srow >= (size_t)a.io_rows) srow -= (size_t)a.io_rows;
+                        const float w = fmaf(-0.46f, __builtin_amdgcn_cosf((float)srow * a.hamming_inv), 0.54f);
+                        x.x *= w; x.y *= w;
+                    } else {
+                        x = cmul(x, a.rowvec[rowi]);
+                    }
+                }
+        }
+    }
     float ati_thr = 0.f;
     double ati_re = 0.0, ati_im = 0.0;
     if constexpr (EPI == AZ_EPI_SCALE_ATI) {       // mask threshold: max over the shards channel 1's focus left
