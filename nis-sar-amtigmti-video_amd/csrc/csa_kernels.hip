@@ -69,14 +69,18 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS, (N == 4096 && MODE == RG_CONV
         if constexpr (MODE == RG_FFT) {
             if (live) {
                 if (a.mulvec) {       // spectrum of the Bluestein filter fused into the forward transform (general.hip)
+                    // all P factors requested before the first product is stored: load, multiply, store per element made every
+                    // load wait for the store in front of it (tools/isa_load_waits.py: 17 of 32 loads waited for alone)
                     const cf* __restrict__ mv = a.mulvec + (size_t)(row % a.mul_period) * N;
+                    cf f[P];
 #pragma unroll
                     for (int b = 0; b < P / RL; ++b)
 #pragma unroll
-                        for (int r = 0; r < RL; ++r) {
-                            const int k = E::out_index(t, b, r);
-                            dst[k] = cmul(v[b * RL + r], mv[k]);
-                        }
+                        for (int r = 0; r < RL; ++r) f[b * RL + r] = mv[E::out_index(t, b, r)];
+#pragma unroll
+                    for (int b = 0; b < P / RL; ++b)
+#pragma unroll
+                        for (int r = 0; r < RL; ++r) dst[E::out_index(t, b, r)] = cmul(v[b * RL + r], f[b * RL + r]);
                     return;
                 }
 #pragma unroll

@@ -688,10 +688,8 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_kernel(RdaArgsDev a, cf* 
 }
 // The same pass with one Doppler row per blockIdx.y and four range samples per thread: everything that depends on the row
 // only (s, 1/s, the span of the migrated axis) comes from a table built at plan creation, so a pixel costs one fused
-// multiply-add for its fractional position instead of three fp64 divisions (0.86 -> ms at 13200 x 7200: profiles/r03_f_*).
-// The bracketing sample is still checked against the actual positions r_axis[j] * s, as np.interp would find it.
-struct __attribute__((aligned(8))) RcmcD2 { double a, b; };       // two neighbouring positions / samples as ONE 16-byte access
-struct __attribute__((aligned(8))) RcmcF4 { float x, y, z, w; };  // (8-byte aligned: the hardware takes an unaligned dwordx4)
+// multiply-add for its fractional position instead of three fp64 divisions (0.86 -> 0.37 ms at 13200 x 7200: profiles/r03_f_*).
+struct __attribute__((aligned(8))) RcmcF4 { float x, y, z, w; };  // two neighbouring samples as ONE 16-byte access (8-byte aligned: the hardware takes an unaligned dwordx4)
 __global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a, cf* rc_out) {
     const int k = blockIdx.y;
     const double2 sc = a.rowc[k];
@@ -703,27 +701,29 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a,
     const int last = a.n_r - 1;
     int ko = k + a.out_shift;
     if (ko >= a.n_p) ko -= a.n_p;
-    // A thread's four pixels first request everything the estimated bracket jc = floor(u) needs (its two positions and its two
-    // samples), then decide: written pixel by pixel with the two correction loops in between, a pixel was three dependent
-    // loads deep and the four ran one after the other - the launch was bound by that latency chain, not by its traffic.
-    // The loops stay, for the pixel whose estimate is one off (fp rounding of u at an integer), as the rare slow path.
-    double rj[4], xa[4], xb[4];
+    // The range axis is affine in the sample index to an ulp (:370-373,407), so the positions r_j and the bracket's two positions
+    // come from r_0 + j dr instead of the table: per pixel the table cost 24 bytes from L2 beside the 16 bytes of the bracket's
+    // samples, in a launch that moves 16 bytes per pixel through HBM.  Linear interpolation is continuous in the position, so a
+    // bracket chosen one ulp differently at a tie gives the same value; only the two ENDS of the span decide between a value
+    // and zero (np.interp left = right = 0), and they are taken from the table itself (x_first, x_last above; the last
+    // sample's own position below).  A thread's four gathers are issued before anything waits for them.
+    const double dr = 1.0 / a.inv_dr, r_last = a.r_axis[last];
+    double rj[4], x0[4];
     int jc[4];
-    cf p[4], q[4];
+    RcmcF4 pq[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int j = blockIdx.x * 1024 + m * 256 + threadIdx.x;
-        rj[m] = a.r_axis[j < a.n_r ? j : last];
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
+        const int jj = j < a.n_r ? j : last;
+        rj[m] = jj == last ? r_last : fma((double)jj, dr, r0);
         int c = (int)floor(fma(rj[m], c_a, -c_b));
         c = c < 0 ? 0 : (c > last - 1 ? last - 1 : c);
-        jc[m] = c;
-        const RcmcD2 xr = *reinterpret_cast<const RcmcD2*>(a.r_axis + c);
-        const RcmcF4 pq = *reinterpret_cast<const RcmcF4*>(row + c);
-        xa[m] = xr.a; xb[m] = xr.b;
-        p[m] = make_float2(pq.x, pq.y); q[m] = make_float2(pq.z, pq.w);
+        double xa = fma((double)c, dr, r0) * s;
+        const double xb = (c + 1 == last ? r_last : fma((double)(c + 1), dr, r0)) * s;
+        if (c > 0 && xa > rj[m]) { --c; xa = fma((double)c, dr, r0) * s; }            // u rounded across an integer
+        else if (c < last - 1 && xb <= rj[m]) { ++c; xa = xb; }
+        jc[m] = c; x0[m] = xa;
+        pq[m] = *reinterpret_cast<const RcmcF4*>(row + c);
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -731,17 +731,8 @@ __global__ __launch_bounds__(256) void rda_rcmc_azcomp_rows_kernel(RdaArgsDev a,
         if (j >= a.n_r) continue;
         cf y = make_float2(0.f, 0.f);
         if (rj[m] >= x_first && rj[m] <= x_last) {
-            double x0 = xa[m] * s;
-            cf pp = p[m], qq = q[m];
-            int j0 = jc[m];
-            if ((j0 > 0 && x0 > rj[m]) || (j0 < last - 1 && xb[m] * s <= rj[m])) {      // estimate one off: np.interp's bracket by search
-                while (j0 > 0 && a.r_axis[j0] * s > rj[m]) --j0;
-                while (j0 < last - 1 && a.r_axis[j0 + 1] * s <= rj[m]) ++j0;
-                x0 = a.r_axis[j0] * s;
-                pp = row[j0]; qq = row[j0 + 1];
-            }
-            const float f = (float)((rj[m] - x0) * c_a);
-            y = make_float2(fmaf(f, qq.x - pp.x, pp.x), fmaf(f, qq.y - pp.y, pp.y));
+            const float f = (float)((rj[m] - x0[m]) * c_a);
+            y = make_float2(fmaf(f, pq[m].z - pq[m].x, pq[m].x), fmaf(f, pq[m].w - pq[m].y, pq[m].y));
         }
         const size_t i = (size_t)k * a.n_r + j;
         if (rc_out) rc_out[i] = y;

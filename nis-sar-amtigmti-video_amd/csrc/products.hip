@@ -297,17 +297,24 @@ hipError_t launch_max_abs_f32(const float* x, size_t n, float* out, hipStream_t 
 // ------------------------------------------------------------------------------
 // corner turn: out[c][r] = in[r][c].  64x64 complex64 tiles staged through a
 // padded LDS image; both the read and the write are 512-byte row segments.
+// A thread's sixteen loads are issued before the first of them is used: written as `if (inside) tile[..] = in[..]` every
+// load was waited for inside its own predicated block before the next was issued (tools/isa_load_waits.py: 16 loads, 16
+// waits to zero).  16384^2: 0.986 -> 0.864 ms = 4.97 TB/s = 0.62 of 8 TB/s; 32768 x 2048: 0.246 -> 0.197 ms; nontemporal
+// accesses, which help the azimuth tiles, cost 4 % here (profiles/r05_bf_corner_turn.log).
 // ------------------------------------------------------------------------------
 static constexpr int CT = 64;
 __global__ __launch_bounds__(256) void corner_turn_kernel(const cf* __restrict__ in, cf* __restrict__ out, int rows, int cols) {
     __shared__ cf tile[CT][CT + 1];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 x 4
     const int r0 = blockIdx.y * CT, c0 = blockIdx.x * CT;
+    cf v[CT / 4];
 #pragma unroll
     for (int k = 0; k < CT; k += 4) {
         const int r = r0 + ty + k, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + k][tx] = in[(size_t)r * cols + c];
+        v[k / 4] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : make_float2(0.f, 0.f);
     }
+#pragma unroll
+    for (int k = 0; k < CT; k += 4) tile[ty + k][tx] = v[k / 4];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < CT; k += 4) {

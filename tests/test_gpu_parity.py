@@ -379,6 +379,21 @@ def test_corner_turn_multilook_noise(sx, ctx):
     assert abs(a.real.std() - 1) < 0.01 and abs(a.imag.std() - 1) < 0.01 and abs(a.mean()) < 0.01
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 1), (65, 3), (100, 77), (7199, 40), (64, 8192), (9000, 8200)])
+def test_corner_turn_ragged_and_streaming(sx, ctx, rows, cols, monkeypatch):
+    """sarx_corner_turn_dev moves bits only: ragged edge tiles (nothing read or written outside the image: the buffers are
+    exactly image-sized and the neighbours are checked) and the nontemporal form large images take (9000 x 8200 = 563 MiB)."""
+    x = _rand((rows, cols), rows + cols)
+    guard = np.complex64(7 - 3j)
+    d_in = ctx.to_device(x)
+    d_out = ctx.to_device(np.full(rows * cols + 128, guard, np.complex64))
+    ctx.corner_turn(d_in, d_out, rows, cols)
+    out = d_out.download(np.complex64, (rows * cols + 128,))
+    np.testing.assert_array_equal(out[: rows * cols].reshape(cols, rows), x.T)
+    assert (out[rows * cols:] == guard).all()
+    d_in.release(); d_out.release()
+
+
 @pytest.mark.parametrize("n_az,n_rg,looks", [(512, 1024, 16), (128, 256, 4), (2048, 512, 32), (64, 64, 1)])
 def test_fused_look_slot(sx, ctx, n_az, n_rg, looks):
     """sarx_csa_plan_set_look_slot: the multilooked intensity emitted by the focus itself equals the mean of |image|^2 over

@@ -1,6 +1,6 @@
 import os, sys, time, cProfile, pstats
 import numpy as np
-sys.path.insert(0, "nis-sar-amtigmti-video_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nis-sar-amtigmti-video_amd"))
 import sarx
 from sarx.targets import generate_destroyer
 k = sarx.batch_constants(); tg = generate_destroyer(center_pos=(0,0,0))
