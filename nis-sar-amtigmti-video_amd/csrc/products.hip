@@ -429,9 +429,7 @@ struct Rng {
         const float u1 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
         const float u2 = ((float)(uint32_t)((h >> 8) & 0xFFFFFF)) * (1.0f / 16777216.0f);
         const float r = sqrtf(-2.0f * __logf(u1));
-        float s, c;
-        __sincosf(6.28318530718f * u2, &s, &c);
-        return make_float2(r * c, r * s);
+        return make_float2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));     // v_sin / v_cos take revolutions
     }
 };
 __device__ float gamma_unit_mean(Rng& g, float nu) {
@@ -462,13 +460,23 @@ __global__ __launch_bounds__(256) void ocean_noise_kernel(cf* buf, size_t n, flo
         x.x += sigma * th.x;
         x.y += sigma * th.y;
         if (clutter_power > 0.f) {
-            const float tex = gamma_unit_mean(g, nu);
-            const float spk = -__logf(g.uniform());
+            float tex, spk;
+            if (nu == 1.0f) {
+                // shape 1 - K_NU of every script of the reference (sar_satellite_sim.py:317, sar_vehicle_sim.py:138, sar_batch_sim.py:49):
+                // Gamma(1, 1) IS Exp(1), so texture and speckle are two logarithms of one hash's two 24-bit halves.  The rejection
+                // loop below runs until the LAST lane of a wave accepts (all 64 in the first round: 0.95^64 = 4 %), two to three
+                // rounds of a normal pair, a uniform and two logarithms: 0.54 -> ms per 2500 x 22004 VideoSAR frame.
+                const uint64_t h = g.next();
+                tex = -__logf(((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f));
+                spk = -__logf(((float)(uint32_t)((h >> 16) & 0xFFFFFF) + 0.5f) * (1.0f / 16777216.0f));
+            } else {
+                tex = gamma_unit_mean(g, nu);
+                spk = -__logf(g.uniform());
+            }
             const float amp = sqrtf(clutter_power * tex * spk);
-            float s, c;
-            __sincosf(6.28318530718f * g.uniform(), &s, &c);
-            x.x += amp * c;
-            x.y += amp * s;
+            const float u = g.uniform();
+            x.x += amp * __builtin_amdgcn_cosf(u);
+            x.y += amp * __builtin_amdgcn_sinf(u);
         }
         buf[i] = x;
     }

@@ -39,6 +39,20 @@ def test_k_clutter_moments(k_nu):
     assert abs(np.mean(np.exp(1j * ph))) < 0.005
 
 
+def test_k_clutter_shape_one_is_the_exponential_texture():
+    """K_NU = 1.0 in every script of the reference: Gamma(1, 1) = Exp(1), drawn as -log(u) beside the speckle from one hash.
+    Third intensity moment E[I^3] = Pc^3 E[G^3] E[E^3] = 36 Pc^3, texture and speckle independent of the phase, and the
+    real and imaginary parts uncorrelated."""
+    pc = 2.0 / 10 ** 1.0
+    x = _noise(1 << 22, 2.0, 80.0, 10.0, 1.0, 11).astype(np.complex128)
+    i = np.abs(x) ** 2
+    assert abs(np.mean(i ** 3) / (36 * pc ** 3) - 1) < 0.12
+    assert abs(np.mean(np.log(i / pc)) - 2 * (-0.5772156649)) < 0.01          # E[log G] + E[log E] = -2 gamma_Euler
+    ph = np.angle(x)
+    assert abs(np.corrcoef(i, np.cos(ph))[0, 1]) < 0.003 and abs(np.corrcoef(i, np.sin(2 * ph))[0, 1]) < 0.003
+    assert abs(np.mean(x.real * x.imag)) < 0.005 * pc
+
+
 def test_reproducible_and_seeded():
     a = _noise(4096, 1.0, 10.0, 10.0, 1.0, 3)
     assert np.array_equal(a, _noise(4096, 1.0, 10.0, 10.0, 1.0, 3))
