@@ -42,6 +42,9 @@ struct RangeArgs {
     // of the result the samples [conv_crop0, conv_crop0 + conv_out) go to the output line (leading dimension conv_out_ld)
     int conv_valid, conv_crop0, conv_out;
     size_t conv_in_ld, conv_out_ld;
+    // RG_CONV on the power-of-two line kernel only: conv_wrap_n > 0 reads input sample j of a line from column (conv_wrap_c0 + j) mod
+    // conv_wrap_n of the dense line (a wrapped segment: the overlap-save blocks of a circular correlation, tdbp.hip)
+    int conv_wrap_n, conv_wrap_c0;
     // optional {first workgroup start, last workgroup end} of this launch in s_memrealtime ticks (100 MHz), reduced with
     // atomic min / max by one lane per workgroup (sarx_csa_plan_stamp_range; range_fused_wl_kernel only): the launch's
     // execution span while other launches share the GPU, which an event pair on the stream cannot separate from queueing

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(RangeCfg<N>::THREADS, (N == 4096 && MODE == RG_CONV
             for (int r = 0; r < R0; ++r) {
                 if constexpr (MODE == RG_CONV) {      // zero padding up to N: neither stored nor read
                     const int j = E::in_index(t, b, r);
-                    v[b * R0 + r] = j < a.conv_valid ? src[j] : make_float2(0.f, 0.f);
+                    int col = j;
+                    if (a.conv_wrap_n > 0) col = (int)((unsigned)(col + a.conv_wrap_c0) % (unsigned)a.conv_wrap_n);
+                    v[b * R0 + r] = j < a.conv_valid ? src[col] : make_float2(0.f, 0.f);
                 } else {
                     v[b * R0 + r] = src[E::in_index(t, b, r)];
                 }

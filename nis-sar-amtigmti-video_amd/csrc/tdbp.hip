@@ -121,6 +121,7 @@ struct Tdbp {
     std::map<int, cf*> hhat;      // conj spectrum of the reference chirp per FFT length (device order)
     int l_ref = 0;
     bool full_rc = false;         // SARX_TDBP_FULL_RC=1: always compress every sample
+    bool three_launch = false;    // SARX_TDBP_RC_FUSED=0: copy-in, two transforms, copy-out per block (the form of rounds 2-4, for A/B)
     int win_lo = 0, win_hi = 0;   // samples compressed by the last call
     PulseGeo* geo = nullptr;
     double *xax = nullptr, *yax = nullptr;
@@ -192,6 +193,7 @@ Tdbp* tdbp_create(int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp
     hipError_t e;
     t->l_ref = l_ref;
     if (const char* ev = getenv("SARX_TDBP_FULL_RC")) t->full_rc = atoi(ev) != 0;
+    if (const char* ev = getenv("SARX_TDBP_RC_FUSED")) t->three_launch = atoi(ev) == 0;
     if ((e = filter_spectrum(t, m, nullptr)) != hipSuccess) return bail("filter spectrum", e);
     if ((e = hipMalloc(&t->work, (size_t)n_pulses * m * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
     if ((e = hipMalloc(&t->rc, (size_t)n_pulses * num_samples * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
@@ -209,6 +211,17 @@ static hipError_t compress_block(Tdbp* t, const float2* raw, int n0, int cnt, in
     cf* hhat = nullptr;
     TCK(filter_spectrum(t, m, &hhat));
     const int n = t->n_s;
+    if (m <= 16384 && !t->three_launch) {
+        // one launch: the wrapped m-sample segment read straight from the pulse, FFT . conj(reference spectrum) . IFFT in
+        // registers / LDS, the cnt wanted outputs written to their place (range_pass_kernel<m, RG_CONV>): 0.42 -> ms per
+        // 2500 x 22004 frame against copy-in, two transforms and copy-out (profiles/r05_bj_*)
+        RangeArgs ca{};
+        ca.in = raw; ca.out = t->rc + n0; ca.tw = t->tw_all + m; ca.n_az = t->n_p; ca.inv_n = 1.0f / (float)m;
+        ca.mulvec = hhat; ca.mul_period = 1;
+        ca.conv_valid = m; ca.conv_crop0 = 0; ca.conv_out = cnt; ca.conv_in_ld = (size_t)n; ca.conv_out_ld = (size_t)n;
+        ca.conv_wrap_n = n; ca.conv_wrap_c0 = n0 % n;
+        return launch_range_pass(m, RG_CONV, ca, st);
+    }
     dim3 grid((m + 255) / 256, t->n_p < 8192 ? t->n_p : 8192);
     hipLaunchKernelGGL(wrap_copy_kernel, grid, dim3(256), 0, st, raw, t->n_p, n, t->work, m, n0);
     TCK(hipGetLastError());
