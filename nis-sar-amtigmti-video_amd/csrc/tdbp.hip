@@ -101,6 +101,94 @@ __global__ __launch_bounds__(256) void tdbp_kernel(TdbpArgs a) {
     if (live) a.part[(size_t)blockIdx.y * a.nx * a.ny + (size_t)iy * a.nx + ix] = make_double2(acc_re, acc_im);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same sum with the geometry expanded about the tile's reference pixel (round 5).  A 16 x 16 tile spans ~10 m at
+// ranges of hundreds of kilometres, so per (tile, pulse) everything that needs a square root or a division is computed
+// ONCE - by one lane per pulse, 256 pulses per batch, handed to the tile through LDS - and a pixel keeps only
+//   d_tx = d0 sqrt(1 + u),  u = (2 D.q + |q|^2) / d0^2        as d0 (1 + u/2 - u^2/8 + u^3/16)   (u <= 5e-5: next term 5 u^4 / 128)
+//   d_tx - d_rx = E0 + grad E . q                             (E = d_tx (1 - sqrt(1 + 4|w|^2/c^2 - 4 r / c)), r = d.w / d_tx: its
+//                                                              leading term (2/c) d.w is exactly linear in q, the rest < 1e-11 m)
+//   t_shift fs = ts0 + grad ts . q                            (fp32: it only moves the interpolation coordinate, by < 1e-6 sample)
+// with q the pixel's offset from the reference pixel (exact differences of the axis tables).  22 fp64 instructions per
+// pixel and pulse instead of 48; the launcher takes this kernel only when 5 u_max^4 / 128 * d_max < 1e-9 m over all
+// pulses (tdbp_tile_ok), otherwise the exact kernel above.  Same pulse order per pixel and the same fp64 accumulation.
+// ------------------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) TilePulse {
+    double a1, a2;           // 2 Dx, 2 Dy
+    double inv_d0sq, d0;
+    double e0, ex;
+    double ey; float ts0, tsx;
+    float tsy, pad0; double pad1;
+};
+static_assert(sizeof(TilePulse) == 80, "five 16-byte LDS reads per pulse");
+static constexpr int TP_BATCH = 256;
+
+__global__ __launch_bounds__(256) void tdbp_tile_kernel(TdbpArgs a) {
+    __shared__ TilePulse s_tp[TP_BATCH];
+    const int tiles_x = (a.nx + 15) >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int ix = tx * 16 + (threadIdx.x & 15), iy = ty * 16 + (threadIdx.x >> 4);
+    const bool live = ix < a.nx && iy < a.ny;
+    const double xc = a.xax[min(tx * 16 + 8, a.nx - 1)], yc = a.yax[min(ty * 16 + 8, a.ny - 1)];
+    const double qx = a.xax[live ? ix : 0] - xc, qy = a.yax[live ? iy : 0] - yc;
+    const double q2 = fma(qx, qx, qy * qy);
+    const float qxf = (float)qx, qyf = (float)qy;
+    const int p0 = blockIdx.y * a.per_chunk, p1 = min(a.n_p, p0 + a.per_chunk);
+    const double two_inv_ns = 2.0 * a.inv_ns;
+    double acc_re = 0.0, acc_im = 0.0;
+    for (int pb = p0; pb < p1; pb += TP_BATCH) {
+        const int nb = min(TP_BATCH, p1 - pb);
+        __syncthreads();                                   // the previous batch has been consumed
+        if ((int)threadIdx.x < nb) {
+            const PulseGeo g = a.geo[pb + threadIdx.x];
+            const double dx = fma(a.vfx, g.dt, xc) - g.px, dy = fma(a.vfy, g.dt, yc) - g.py, dz = a.vfz * g.dt - g.pz;   // :205-208 at the reference pixel
+            const double s0 = fma(dx, dx, fma(dy, dy, dz * dz));
+            const double inv_d = rsqrt(s0), d0 = s0 * inv_d;
+            const double dw = g.wx * dx + g.wy * dy + g.wz * dz;
+            const double r = dw * inv_d;                                                         // :210-212
+            const double tau_a = 2.0 * d0 * a.inv_c;
+            const double eps = tau_a * (2.0 * dw - tau_a * g.pad) * (inv_d * inv_d);
+            const double sm1 = eps * fma(eps, fma(eps, fma(eps, -5.0 / 128.0, -1.0 / 16.0), -1.0 / 8.0), -0.5);   // sqrt(1 - eps) - 1
+            const double ux = dx * inv_d, uy = dy * inv_d;                                      // unit vector, ground components
+            const double f = -sm1, fp = 2.0 * a.inv_c / (1.0 + sm1);                            // F(r) and F'(r)
+            const double rx = (g.wx - r * ux) * inv_d, ry = (g.wy - r * uy) * inv_d;            // grad r
+            TilePulse t;
+            t.a1 = 2.0 * dx; t.a2 = 2.0 * dy; t.inv_d0sq = inv_d * inv_d; t.d0 = d0;
+            t.e0 = d0 * f;
+            t.ex = fma(d0 * fp, rx, f * ux); t.ey = fma(d0 * fp, ry, f * uy);
+            const double ks = a.k_shift * a.fs;
+            t.ts0 = (float)(r * ks); t.tsx = (float)(rx * ks); t.tsy = (float)(ry * ks);
+            t.pad0 = 0.f; t.pad1 = 0.0;
+            s_tp[threadIdx.x] = t;
+        }
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            const TilePulse& t = s_tp[k];
+            const double u = fma(t.a1, qx, fma(t.a2, qy, q2)) * t.inv_d0sq;
+            const double h = u * fma(u, fma(u, 1.0 / 16.0, -1.0 / 8.0), 0.5);
+            const double d_tx = fma(t.d0, h, t.d0);
+            const double e = fma(t.ex, qx, fma(t.ey, qy, t.e0));                                // d_tx - d_rx
+            const double tau = fma(2.0, d_tx, -e) * a.inv_c;                                   // :219
+            const float ts = fmaf(t.tsx, qxf, fmaf(t.tsy, qyf, t.ts0));                         // t_shift * fs (:213)
+            const double idx_f = fma(tau - a.t_start, a.fs, (double)ts);                        // :221
+            const float xn = (float)fma(idx_f, two_inv_ns, -1.0);                               // :222, .float() :226
+            const float x = __fmaf_rn(xn + 1.0f, a.half_w, -0.5f);                              // grid_sample unnormalise
+            const float x0 = floorf(x);
+            const float w = x - x0, ew = 1.0f - w;
+            const int i0 = (int)x0;
+            const cf* row = a.rc + (size_t)(pb + k) * a.n_s;
+            cf v0 = make_float2(0.f, 0.f), v1 = v0;
+            if (i0 >= 0 && i0 < a.n_s) v0 = row[i0];
+            if (i0 + 1 >= 0 && i0 + 1 < a.n_s) v1 = row[i0 + 1];
+            const float s_re = fmaf(v1.x, w, v0.x * ew), s_im = fmaf(v1.y, w, v0.y * ew);
+            const cf ph = cis_rev(a.fc * tau);                                                  // :231-232
+            acc_re += (double)(s_re * ph.x - s_im * ph.y);
+            acc_im += (double)(s_re * ph.y + s_im * ph.x);
+        }
+    }
+    if (live) a.part[(size_t)blockIdx.y * a.nx * a.ny + (size_t)iy * a.nx + ix] = make_double2(acc_re, acc_im);
+}
+
 __global__ __launch_bounds__(256) void tdbp_reduce_kernel(const double2* part, int chunks, size_t n_pix, double2* out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pix) return;
@@ -275,6 +363,28 @@ static void sample_window(const Tdbp* t, const std::vector<PulseGeo>& geo, const
     *hi = u < 0 ? 0 : (u > (double)t->n_s ? t->n_s : (int)u);
 }
 
+// May the tile kernel stand in for the exact one?  Farthest pixel of a 16 x 16 tile from its reference pixel (index 8 of 16) against
+// the nearest range of any pulse: the first omitted series term of d_tx, 5 u^4 / 128 * d, must stay below 1e-9 m (4e-7 rad of
+// carrier phase at X band).  SARX_TDBP_TILE=0 forces the exact kernel (A/B).
+static bool tdbp_tile_ok(const Tdbp* t, const std::vector<PulseGeo>& geo, const double* vf, double scene_size) {
+    if (const char* ev = getenv("SARX_TDBP_TILE")) if (atoi(ev) == 0) return false;
+    if (t->nx < 2 || t->ny < 2) return false;
+    const double h = scene_size / 2;
+    const double qm = 8.0 * hypot(scene_size / (double)(t->nx - 1), scene_size / (double)(t->ny - 1));
+    for (const PulseGeo& g : geo) {
+        const double sx = vf[0] * g.dt, sy = vf[1] * g.dt, gz = vf[2] * g.dt - g.pz;
+        const double qx = g.px - sx, qy = g.py - sy;
+        const double cx = qx < -h ? -h : (qx > h ? h : qx), cy = qy < -h ? -h : (qy > h ? h : qy);
+        const double dmin = sqrt((cx - qx) * (cx - qx) + (cy - qy) * (cy - qy) + gz * gz);
+        const double ax = fabs(qx) + h, ay = fabs(qy) + h;
+        const double dmax = sqrt(ax * ax + ay * ay + gz * gz);
+        if (!(dmin > 0.0)) return false;
+        const double u = 2.0 * qm / dmin + (qm / dmin) * (qm / dmin);
+        if (!(5.0 / 128.0 * u * u * u * u * dmax < 1e-9)) return false;
+    }
+    return true;
+}
+
 static void linspace(double a, double b, int n, std::vector<double>& out) {     // numpy.linspace (:173-174)
     out.resize(n);
     const double step = n > 1 ? (b - a) / (double)(n - 1) : 0.0;
@@ -315,7 +425,8 @@ hipError_t tdbp_focus(Tdbp* t, const float2* raw, const double* pos, const doubl
     a.inv_ns = 1.0 / (double)t->n_s; a.half_w = (float)t->n_s / 2.0f;
     a.n_p = t->n_p; a.n_s = t->n_s; a.nx = t->nx; a.ny = t->ny; a.per_chunk = t->per_chunk;
     const int tiles = ((t->nx + 15) / 16) * ((t->ny + 15) / 16);
-    hipLaunchKernelGGL(tdbp_kernel, dim3(tiles, t->chunks), dim3(256), 0, st, a);
+    if (tdbp_tile_ok(t, geo, vel_focus, scene_size)) hipLaunchKernelGGL(tdbp_tile_kernel, dim3(tiles, t->chunks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(tdbp_kernel, dim3(tiles, t->chunks), dim3(256), 0, st, a);
     TCK(hipGetLastError());
     const size_t n_pix = (size_t)t->nx * t->ny;
     hipLaunchKernelGGL(tdbp_reduce_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, st, t->part, t->chunks, n_pix, t->img);

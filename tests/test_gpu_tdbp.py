@@ -107,6 +107,25 @@ def test_device_resident_chain_and_chunking():
     assert np.abs(a).max() > 1.5 * np.abs(c).max()
 
 
+@pytest.mark.parametrize("speed,heading", [(15.0, 45.0), (0.0, 0.0)])
+def test_tile_expansion_equals_exact_kernel(speed, heading, monkeypatch):
+    """Metre-sized pixels at the script's own geometry (sar_batch_sim.py:12-50: 500 km range) take the kernel that expands the
+    geometry about each 16 x 16 tile's reference pixel; SARX_TDBP_TILE=0 forces the exact per-pixel kernel.  320 pulses cross a
+    256-pulse batch and several chunks; 90 x 70 pixels leave ragged tiles.  Both against each other and against the oracle."""
+    import sarx
+    k = tb.batch_constants()
+    sc = tb.tdbp_scene(n_pulses=320, seed=21, k=k, speed=speed, heading_deg=heading, swath=90.0, n_targets=4)
+    raw = sc["raw"].astype(np.complex64)
+    args = (raw, sc["pos"], sc["vel"], sc["t_start"], sc["num_samples"], sc["v_tgt"], sc["t_vec"], sc["swath"])
+    tile = sarx.tdbp_gpu(*args, nx=90, ny=70, consts=k)
+    monkeypatch.setenv("SARX_TDBP_TILE", "0")
+    exact = sarx.tdbp_gpu(*args, nx=90, ny=70, consts=k)
+    assert not np.array_equal(tile, exact)                       # two different kernels ran
+    assert rel_l2(tile, exact) < 2e-6
+    ref = tb.tdbp(raw, sc["pos"], sc["vel"], sc["t_start"], sc["num_samples"], sc["v_tgt"], sc["t_vec"], sc["swath"], 90, 70, k)
+    assert rel_l2(tile, ref) < TOL and rel_l2(exact, ref) < TOL
+
+
 def test_tdbp_errors():
     import sarx
     k = tb.scaled_constants()
