@@ -20,6 +20,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -211,8 +212,15 @@ struct Tdbp {
     bool full_rc = false;         // SARX_TDBP_FULL_RC=1: always compress every sample
     bool three_launch = false;    // SARX_TDBP_RC_FUSED=0: copy-in, two transforms, copy-out per block (the form of rounds 2-4, for A/B)
     int win_lo = 0, win_hi = 0;   // samples compressed by the last call
-    PulseGeo* geo = nullptr;
+    // per-pulse table, double-buffered: frame i + 1's table is staged in page-locked memory and copied on the stream while frame i
+    // still reads its own - no stream synchronisation per frame (the copy of rounds 2-4 was a blocking one behind a hipStreamSynchronize
+    // that made the host wait for the frame's echo, noise and range compression before it could enqueue the back-projection)
+    PulseGeo* geo[2] = {nullptr, nullptr};
+    PulseGeo* h_geo[2] = {nullptr, nullptr};
+    hipEvent_t geo_done[2] = {nullptr, nullptr};
+    int geo_slot = 0;
     double *xax = nullptr, *yax = nullptr;
+    double axes_scene = -1.0;     // scene_size the pixel axes on the device were built for
     double2 *part = nullptr, *img = nullptr;
     uint64_t bytes = 0;
 };
@@ -220,7 +228,12 @@ struct Tdbp {
 void tdbp_destroy(Tdbp* t) {
     if (!t) return;
     for (auto& kv : t->hhat) hipFree(kv.second);
-    hipFree(t->work); hipFree(t->rc); hipFree(t->geo); hipFree(t->xax); hipFree(t->yax);
+    hipFree(t->work); hipFree(t->rc); hipFree(t->xax); hipFree(t->yax);
+    for (int b = 0; b < 2; ++b) {
+        hipFree(t->geo[b]);
+        if (t->h_geo[b]) hipHostFree(t->h_geo[b]);
+        if (t->geo_done[b]) hipEventDestroy(t->geo_done[b]);
+    }
     hipFree(t->part); hipFree(t->img);
     delete t;
 }
@@ -285,7 +298,11 @@ Tdbp* tdbp_create(int n_pulses, int num_samples, int nx, int ny, const sarx_tdbp
     if ((e = filter_spectrum(t, m, nullptr)) != hipSuccess) return bail("filter spectrum", e);
     if ((e = hipMalloc(&t->work, (size_t)n_pulses * m * sizeof(cf))) != hipSuccess) return bail("hipMalloc work", e);
     if ((e = hipMalloc(&t->rc, (size_t)n_pulses * num_samples * sizeof(cf))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc(&t->geo, (size_t)n_pulses * sizeof(PulseGeo))) != hipSuccess) return bail("hipMalloc", e);
+    for (int b = 0; b < 2; ++b) {
+        if ((e = hipMalloc(&t->geo[b], (size_t)n_pulses * sizeof(PulseGeo))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipHostMalloc(&t->h_geo[b], (size_t)n_pulses * sizeof(PulseGeo), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+        if ((e = hipEventCreateWithFlags(&t->geo_done[b], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    }
     if ((e = hipMalloc(&t->xax, (size_t)nx * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&t->yax, (size_t)ny * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&t->part, (size_t)t->chunks * n_pix * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
@@ -396,6 +413,8 @@ static void linspace(double a, double b, int n, std::vector<double>& out) {     
 // all_samples: compress every sample of every pulse (the caller wants rc_data), else only the window the scene can touch
 hipError_t tdbp_focus(Tdbp* t, const float2* raw, const double* pos, const double* vel, const double* t_pulses, double t_start,
                       const double* vel_focus, double scene_size, bool all_samples, hipStream_t st) {
+    const int slot = (t->geo_slot ^= 1);
+    TCK(hipEventSynchronize(t->geo_done[slot]));           // the focus two calls ago has finished with this slot (returns at once as a rule)
     std::vector<PulseGeo> geo(t->n_p);
     double mean = 0.0;
     for (int p = 0; p < t->n_p; ++p) mean += t_pulses[p];
@@ -406,19 +425,22 @@ hipError_t tdbp_focus(Tdbp* t, const float2* raw, const double* pos, const doubl
         g.wx = vel[3 * p] - vel_focus[0]; g.wy = vel[3 * p + 1] - vel_focus[1]; g.wz = vel[3 * p + 2] - vel_focus[2];
         g.dt = t_pulses[p] - mean; g.pad = g.wx * g.wx + g.wy * g.wy + g.wz * g.wz;
     }
-    std::vector<double> xa, ya;
-    linspace(-scene_size / 2, scene_size / 2, t->nx, xa);
-    linspace(-scene_size / 2, scene_size / 2, t->ny, ya);
     int lo = 0, hi = t->n_s;
     if (!all_samples && !t->full_rc) sample_window(t, geo, vel_focus, t_start, scene_size, &lo, &hi);
     TCK(tdbp_range_compress(t, raw, lo, hi, st));
-    // the stream may still be reading the previous call's tables
-    TCK(hipStreamSynchronize(st));
-    TCK(hipMemcpy(t->geo, geo.data(), geo.size() * sizeof(PulseGeo), hipMemcpyHostToDevice));
-    TCK(hipMemcpy(t->xax, xa.data(), xa.size() * sizeof(double), hipMemcpyHostToDevice));
-    TCK(hipMemcpy(t->yax, ya.data(), ya.size() * sizeof(double), hipMemcpyHostToDevice));
+    memcpy(t->h_geo[slot], geo.data(), geo.size() * sizeof(PulseGeo));
+    TCK(hipMemcpyAsync(t->geo[slot], t->h_geo[slot], geo.size() * sizeof(PulseGeo), hipMemcpyHostToDevice, st));
+    if (t->axes_scene != scene_size) {                    // pixel axes: once per scene size (a frame loop keeps it)
+        std::vector<double> xa, ya;
+        linspace(-scene_size / 2, scene_size / 2, t->nx, xa);
+        linspace(-scene_size / 2, scene_size / 2, t->ny, ya);
+        TCK(hipStreamSynchronize(st));                     // an earlier focus may still read the old axes
+        TCK(hipMemcpy(t->xax, xa.data(), xa.size() * sizeof(double), hipMemcpyHostToDevice));
+        TCK(hipMemcpy(t->yax, ya.data(), ya.size() * sizeof(double), hipMemcpyHostToDevice));
+        t->axes_scene = scene_size;
+    }
     TdbpArgs a{};
-    a.rc = t->rc; a.geo = t->geo; a.xax = t->xax; a.yax = t->yax; a.part = t->part;
+    a.rc = t->rc; a.geo = t->geo[slot]; a.xax = t->xax; a.yax = t->yax; a.part = t->part;
     a.vfx = vel_focus[0]; a.vfy = vel_focus[1]; a.vfz = vel_focus[2];
     a.inv_c = 1.0 / t->k.c; a.fc = t->k.fc; a.fs = t->k.fs; a.t_start = t_start;
     a.k_shift = -t->k.fc * 2.0 / t->k.c / t->k.k_rate;
@@ -430,7 +452,8 @@ hipError_t tdbp_focus(Tdbp* t, const float2* raw, const double* pos, const doubl
     TCK(hipGetLastError());
     const size_t n_pix = (size_t)t->nx * t->ny;
     hipLaunchKernelGGL(tdbp_reduce_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, st, t->part, t->chunks, n_pix, t->img);
-    return hipGetLastError();
+    TCK(hipGetLastError());
+    return hipEventRecord(t->geo_done[slot], st);
 }
 
 const double2* tdbp_image(const Tdbp* t) { return t->img; }

@@ -12,6 +12,7 @@
 #   smoke                        __graft_entry__.smoke()                                    -> smoke.log
 #   bench <name> [bench args]    python bench.py ...                                        -> bench_<name>.json / .err
 #   prof <name> <script> [args]  rocprofv3 --kernel-trace --stats -- python3 <script> ...   -> <name>_kernel_stats.csv, <name>_profiled.log
+#   trace <name> <script> [args] rocprofv3 --kernel-trace -- python3 <script> ...           -> <name>_kernel_trace.csv.gz, <name>_busy.log
 #   py <name> <script> [args]    python3 <script> ...                                       -> <name>.log
 #   bin <name> <source.hip> [args]  hipcc -O3 the micro-benchmark if its .bin is missing, run it  -> <name>.log
 #   pmc <name> <counters> <script> [args]   one rocprofv3 --pmc pass (counters comma separated, kernel trace only) -> pmc_<name>/
@@ -45,6 +46,19 @@ step_prof() {
   [ -n "$f" ] && cp "$f" "$O/${name}_kernel_stats.csv" && head -8 "$O/${name}_kernel_stats.csv" | cut -c1-170
   rm -rf "/tmp/prof_$name"
   [ $rc -eq 0 ] || tail -15 "$O/${name}_profiled.log"
+  return $rc
+}
+step_trace() {   # kernel trace kept as a CSV (gzip) + tools/trace_busy.py summary: where the GPU idles inside a frame loop
+  local name=$1; shift
+  local script=$1; shift
+  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d "/tmp/trace_$name" -- python3 "$R/$script" "$@" > "$R/$O/${name}_traced.log" 2>&1 ); local rc=$?
+  local f; f=$(find "/tmp/trace_$name" -name "*kernel_trace.csv" 2>/dev/null | head -1)
+  if [ -n "$f" ]; then
+    python3 "$R/tools/trace_busy.py" "$f" > "$O/${name}_busy.log" 2>&1; tail -${GPU_CALL_TAIL:-30} "$O/${name}_busy.log"
+    gzip -c "$f" > "$O/${name}_kernel_trace.csv.gz"
+  fi
+  rm -rf "/tmp/trace_$name"
+  [ $rc -eq 0 ] || tail -15 "$O/${name}_traced.log"
   return $rc
 }
 step_py() {
