@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SARX_VERSION 206   /* 206: sarx_rda_focus_host2 / _dev2 (the airborne script's eighth output, the azimuth-compressed map); 205: sarx_csa_plan_stamp_range (execution span of the fused range launch from in-kernel clock stamps), overlapped host transfers (sarx_memcpy_h2d_unordered, sarx_memcpy_d2h_begin / _end, sarx_csa_focus_host_begin / _end); 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
+#define SARX_VERSION 206   /* 206: sarx_rda_focus_host2 / _dev2 (the airborne script's eighth output, the azimuth-compressed map), sarx_memcpy_h2d_lane; 205: sarx_csa_plan_stamp_range (execution span of the fused range launch from in-kernel clock stamps), overlapped host transfers (sarx_memcpy_h2d_unordered, sarx_memcpy_d2h_begin / _end, sarx_csa_focus_host_begin / _end); 204: sarx_max_abs_f32_dev, sarx_allreduce_max_dev (global normalisation of a frame stack), sarx_host_alloc / _free, lanes (sarx_select_lane, sarx_lanes_join), sarx_add_ocean_noise_rel_dev, sarx_probe_lanes; 203: permuted-spectrum pass ids 12 / 13; a focus with sarx_csa_plan_set_ati armed no longer clears the max slot */
 
 typedef struct sarx_ctx sarx_ctx;
 typedef struct sarx_plan sarx_plan;
@@ -111,6 +111,10 @@ int sarx_memcpy_d2h(sarx_ctx* ctx, void* dst_host, const void* src_dev, size_t b
  *   on the ctx's download stream, ordered after everything enqueued so far on the current lane; *out_slot identifies it (eight may be
  *   in flight).  sarx_memcpy_d2h_end(slot) blocks until that copy has landed.  sarx_sync waits for all of them too. */
 int sarx_memcpy_h2d_unordered(sarx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+/* sarx_memcpy_h2d_lane: sarx_memcpy_h2d that waits for the CURRENT lane's enqueued work only (sarx_memcpy_h2d waits for every lane):
+ * for a table only this lane's launches read - the per-frame tables of a frame loop with frames in flight on other lanes
+ * (sar_batch_sim.py:303-331), which a wait for every lane would drain at every upload. */
+int sarx_memcpy_h2d_lane(sarx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int sarx_memcpy_d2h_begin(sarx_ctx* ctx, void* dst_host_pinned, const void* src_dev, size_t bytes, int* out_slot);
 int sarx_memcpy_d2h_end(sarx_ctx* ctx, int slot);
 int sarx_memcpy_d2d(sarx_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);

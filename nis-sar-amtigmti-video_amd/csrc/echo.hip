@@ -39,16 +39,17 @@ __global__ __launch_bounds__(ECHO_THREADS) void echo_synth_kernel(EchoArgs a) {
         __syncthreads();
         if (b < a.n_targets) {
             const double2 tp = a.tau_pb[(size_t)i * a.n_targets + b];
-            s_tau[threadIdx.x] = tp.x;
+            s_tau[threadIdx.x] = tp.x + a.u_off;       // u = t_fast - (tau + Tp/2): one subtraction per target-sample instead of two
             s_pb[threadIdx.x] = tp.y;
             s_amp[threadIdx.x] = a.amp_pt ? a.amp_pt[(size_t)i * a.n_targets + b] : a.amp[b];
         }
         __syncthreads();
         const int nb = min(ECHO_THREADS, a.n_targets - b0);
         for (int k = 0; k < nb; ++k) {
-            const double u = (tf - s_tau[k]) - a.u_off;          // (:290,293 / :164,166)
+            const double u = tf - s_tau[k];                      // (:290,293 / :164,166)
             const float gate = (fabs(u) <= half_tp) ? s_amp[k] : 0.f;
-            const cf e = cis_rev(fma(hk * u, u, s_pb[k]));      // phase_base + pi k u^2, in revolutions
+            // phase_base + pi k u^2 in revolutions; its fractional part by v_fract_f64 (one instruction; p - rint(p) is two)
+            const cf e = cis_frac((float)__builtin_amdgcn_fract(fma(hk * u, u, s_pb[k])));
             acc_re = fmaf(gate, e.x, acc_re);
             acc_im = fmaf(gate, e.y, acc_im);
         }

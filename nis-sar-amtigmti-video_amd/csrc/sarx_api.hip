@@ -247,10 +247,14 @@ static CopyOps g_ops;
 // (the reference's arrays are complex128; a NumPy astype of 2^28 elements costs more than the whole transfer)
 // ordered = false (uploads into a buffer no enqueued work touches, downloads of data already complete): the copy does not wait for
 // the lanes and runs on streams of its own, so it overlaps whatever the GPU is doing
-static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, bool narrow = false, bool ordered = true) {
+// ordered: the copy waits for every lane's enqueued work (the buffer may have been written on any of them); lane_only: it waits for
+// the CURRENT lane only and is issued behind it (a table that only this lane's launches read: the other lanes keep running)
+static hipError_t staged_copy(sarx_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, bool narrow = false, bool ordered = true,
+                              bool lane_only = false) {
     const CopyOps& o = g_ops;
     hipError_t e = hipSuccess;
-    if (ordered)
+    if (ordered && lane_only) e = o.stream_sync(c->stream);
+    else if (ordered)
         for (int k = 0; k < sarx_ctx::LANES && e == hipSuccess; ++k)
             if (c->lane[k]) e = o.stream_sync(c->lane[k]);
     if (e != hipSuccess) return e;
@@ -475,6 +479,12 @@ int sarx_memcpy_d2h(sarx_ctx* c, void* d, const void* s, size_t n) {
 int sarx_memcpy_d2d(sarx_ctx* c, void* d, const void* s, size_t n) {
     NEED_CTX(c);
     HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream));
+    return SARX_OK;
+}
+int sarx_memcpy_h2d_lane(sarx_ctx* c, void* d, const void* s, size_t n) {
+    NEED_CTX(c);
+    if (!d || !s) return fail(c, SARX_ERR_INVALID, "NULL pointer");
+    HIPCHK(c, staged_copy(c, d, s, n, true, false, /*ordered=*/true, /*lane_only=*/true));
     return SARX_OK;
 }
 int sarx_memcpy_h2d_unordered(sarx_ctx* c, void* d, const void* s, size_t n) {

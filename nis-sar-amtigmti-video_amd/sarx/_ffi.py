@@ -65,6 +65,7 @@ SIGNATURES = {
     "sarx_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_h2d_unordered": (_i, [_vp, _vp, _vp, _sz]),
+    "sarx_memcpy_h2d_lane": (_i, [_vp, _vp, _vp, _sz]),
     "sarx_memcpy_d2h_begin": (_i, [_vp, _vp, _vp, _sz, _P(_i)]),
     "sarx_memcpy_d2h_end": (_i, [_vp, _i]),
     "sarx_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),

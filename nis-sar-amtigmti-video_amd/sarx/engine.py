@@ -42,6 +42,15 @@ class DeviceBuffer:
         check(self.ctx.lib.sarx_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes), self.ctx.h)
         return self
 
+    def upload_lane(self, arr):
+        """upload() that waits for the current lane's enqueued work only (sarx_memcpy_h2d_lane): for a buffer only this lane's launches
+        read, so that frames in flight on the other lanes keep running (upload() waits for every lane)."""
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > self.nbytes:
+            raise ValueError("upload larger than buffer")
+        check(self.ctx.lib.sarx_memcpy_h2d_lane(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes), self.ctx.h)
+        return self
+
     def upload_unordered(self, arr):
         """upload() that does not wait for GPU work already enqueued: the caller guarantees nothing enqueued touches this buffer, and
         the copy then overlaps whatever the GPU is doing (sarx_memcpy_h2d_unordered)."""
@@ -223,8 +232,10 @@ class Context:
         return b
 
     def scratch_upload(self, tag, arr):
+        """The (tag, current lane) scratch buffer is read by this lane's launches only: the upload waits for this lane alone.  (Waiting
+        for every lane drained the GPU at each of a frame's seven table uploads: 58 % idle in the VideoSAR loop, tools/trace_busy.py.)"""
         arr = np.ascontiguousarray(arr)
-        return self.scratch(tag, arr.nbytes).upload(arr)
+        return self.scratch(tag, arr.nbytes).upload_lane(arr)
 
     # -- pooled page-locked result arrays --
     def last_error(self):

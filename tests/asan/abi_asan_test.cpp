@@ -74,6 +74,7 @@ static void argument_checking() {
     CHECK(sarx_memcpy_d2h(nullptr, buf, buf, 1) != SARX_OK);
     CHECK(sarx_memcpy_d2d(nullptr, buf, buf, 1) != SARX_OK);
     CHECK(sarx_memcpy_h2d_unordered(nullptr, buf, buf, 1) != SARX_OK);
+    CHECK(sarx_memcpy_h2d_lane(nullptr, buf, buf, 1) != SARX_OK);
     CHECK(sarx_memcpy_d2h_begin(nullptr, buf, buf, 1, &i) != SARX_OK);
     CHECK(sarx_memcpy_d2h_end(nullptr, 0) != SARX_OK);
     CHECK(sarx_memcpy2d_d2h(nullptr, buf, 8, buf, 8, 8, 1) != SARX_OK);

@@ -33,10 +33,10 @@ ctx.record(1)
 ms = ctx.elapsed_ms(0, 1)
 ts = float(nt) * npulse * ns
 print(f"echo synth {nt} targets x {npulse} pulses x {ns} samples: {ms:.1f} ms = {ts / ms / 1e6:.1f} G target-samples/s")
-# compute-bound: the roofline is the vector issue rate.  cycles per target-sample from the ISA (tools/isa_slots.py -> profiles/r03_isa_slots.json)
+# compute-bound: the roofline is the vector issue rate.  cycles per target-sample from the ISA (tools/isa_slots.py -> profiles/r05_isa_slots.json)
 import json  # noqa: E402
 try:
-    isa = json.load(open(os.path.join(ROOT, "profiles", "r03_isa_slots.json")))
+    isa = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_slots.json")))
     kk = isa["kernels"]["echo_synth_kernel"]
     need = ts / 64.0 * kk["cycles_per_unit"]                    # SIMD cycles the launch's wave-instructions occupy
     have = isa["n_simd"] * isa["clock_hz"] * ms * 1e-3

@@ -3,7 +3,7 @@
 
     python3 tools/valu_roofline.py profiles/r03_f_videosar_kernel_stats.csv [--echo-targets 35 --pulses 2500 --samples 22004 --nx 512]
 
-frac = (work units / 64 lanes) * (SIMD issue cycles per unit-wave, profiles/r03_isa_slots.json) / (n_SIMD * clock * kernel time):
+frac = (work units / 64 lanes) * (SIMD issue cycles per unit-wave, profiles/r05_isa_slots.json) / (n_SIMD * clock * kernel time):
 the share of the chip's vector issue cycles the kernel's own instruction stream needs (the rest is stalls).  PMC check
 of the instruction counts: tools/pmc_compute.sh (SQ_INSTS_VALU per dispatch)."""
 import argparse
@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--pulses", type=int, default=2500)
     ap.add_argument("--samples", type=int, default=22004)
     ap.add_argument("--nx", type=int, default=512)
-    ap.add_argument("--isa", default=os.path.join(ROOT, "profiles", "r03_isa_slots.json"))
+    ap.add_argument("--isa", default=os.path.join(ROOT, "profiles", "r05_isa_slots.json"))
     a = ap.parse_args()
     isa = json.load(open(a.isa))
     avg = {}
