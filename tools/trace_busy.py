@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """How busy is the GPU inside a frame loop?  From a rocprofv3 --kernel-trace CSV: the union of all kernel intervals against the
-window they span (steady state: the middle 60 % of the launches), the largest idle gaps and what ran on either side of them, and
-per-kernel time inside the window.
+window they span (steady state: the middle 60 % of the launches; gaps longer than 2 ms separate phases of the script - file output
+between two loops - and are reported but not counted as idle time of a loop), the largest idle gaps and what ran on either side of
+them, and per-kernel time inside the window.
     python3 tools/trace_busy.py DIR/*/*_kernel_trace.csv"""
 import collections
 import csv
@@ -24,8 +25,12 @@ for s, e, k in mid[1:]:
     if e >= cur_e:
         last_name = k
 busy += cur_e - cur_s
-span = t1 - t0
-print(f"{len(mid)} launches in {span / 1e6:.3f} ms: GPU busy {busy / span:.3f} of the window, idle {(span - busy) / 1e6:.3f} ms in {len(gaps)} gaps")
+PHASE = 2_000_000
+between = sum(g for g, _, _ in gaps if g > PHASE)
+gaps = [g for g in gaps if g[0] <= PHASE]
+span = t1 - t0 - between
+print(f"{len(mid)} launches in {span / 1e6:.3f} ms of loops (+ {between / 1e6:.1f} ms between phases): GPU busy {busy / span:.3f} of the loops, "
+      f"idle {(span - busy) / 1e6:.3f} ms in {len(gaps)} gaps")
 per = collections.defaultdict(lambda: [0, 0])
 for s, e, k in mid:
     per[k][0] += e - s
