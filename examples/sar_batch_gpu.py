@@ -131,6 +131,11 @@ def main():
             np.savez(out, frames=stack, g_max=g_max, extent=np.array([-v["swath"] / 2, v["swath"] / 2] * 2), fps=FPS)
             print(f"{run_id}: {len(frames)} frames of {len(t_cpi)} pulses x {n_sp} samples -> {a.nx}x{a.nx} in {dt:.2f} s "
                   f"({len(frames) / dt:.1f} frames/s), g_max {g_max:.4g} -> {out}")
+    if world > 1:
+        # leave together: a rank without a file to write reached the end of the script while rank 0 was still saving, and a gloo
+        # process group torn down under a live peer can abort the process (SIGABRT out of a background thread, seen once in nine runs)
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -115,7 +115,8 @@ def test_batch_tdbp_example_two_ranks_equals_one(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "examples", "sar_batch_gpu.py"), *common,
                         "--outdir", str(two)], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    # the launcher's own summary fills the tail of stderr; what a rank printed before it died is further up
+    assert r.returncode == 0, r.stderr[:3000] + "\n...\n" + r.stderr[-1500:]
     for algo in ("mBP", "StdBP"):
         with np.load(one / f"Destroyer_15_90_{algo}.npz") as a, np.load(two / f"Destroyer_15_90_{algo}.npz") as b:
             assert a["frames"].shape == (3, 64, 64)
