@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void ocean_noise_kernel(cf* buf, size_t n, flo
                 // shape 1 - K_NU of every script of the reference (sar_satellite_sim.py:317, sar_vehicle_sim.py:138, sar_batch_sim.py:49):
                 // Gamma(1, 1) IS Exp(1), so texture and speckle are two logarithms of one hash's two 24-bit halves.  The rejection
                 // loop below runs until the LAST lane of a wave accepts (all 64 in the first round: 0.95^64 = 4 %), two to three
-                // rounds of a normal pair, a uniform and two logarithms: 0.54 -> ms per 2500 x 22004 VideoSAR frame.
+                // rounds of a normal pair, a uniform and two logarithms: 0.54 -> 0.24 ms per 2500 x 22004 VideoSAR frame.
                 const uint64_t h = g.next();
                 tex = -__logf(((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f));
                 spk = -__logf(((float)(uint32_t)((h >> 16) & 0xFFFFFF) + 0.5f) * (1.0f / 16777216.0f));
@@ -523,11 +523,23 @@ hipError_t launch_power_stats(const cf* buf, size_t n, double* part, int blocks,
 // The host's finish of the partials and its noise levels, on the device and in the same order and arithmetic: reference power =
 // max |x|^2 (sar_batch_sim.py:313) or mean |x|^2 (sar_satellite_sim.py:333); sigma = sqrt(ref / snr_lin / 2), clutter = ref / scr_lin
 // (scr_lin = 0: thermal noise only) - sar_batch_sim.py:67-78, sar_satellite_sim.py:334-343.
-__global__ void noise_levels_kernel(const double* __restrict__ part, int blocks, double n, int ref_is_max, double snr_lin, double scr_lin,
-                                    float* __restrict__ levels) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One wave: the partials are fetched by all 64 lanes at once into LDS, then lane 0 adds them in block order - the host's order, so the
+// levels stay bit-identical to the two-call form.  With lane 0 fetching them itself every addition waited for its own load from L2:
+// 104 us per frame for 1024 partials, on the critical path of every VideoSAR frame (profiles/r05_bo_videosar_trace_busy.log).
+static constexpr int NOISE_LEVEL_PARTS = 1024;
+__global__ __launch_bounds__(64) void noise_levels_kernel(const double* __restrict__ part, int blocks, double n, int ref_is_max,
+                                                          double snr_lin, double scr_lin, float* __restrict__ levels) {
+    __shared__ double s_part[2 * NOISE_LEVEL_PARTS];
     double sum = 0.0, mx = 0.0;
-    for (int b = 0; b < blocks; ++b) { sum += part[2 * b]; if (part[2 * b + 1] > mx) mx = part[2 * b + 1]; }
+    for (int b0 = 0; b0 < blocks; b0 += NOISE_LEVEL_PARTS) {
+        const int nb = min(NOISE_LEVEL_PARTS, blocks - b0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * nb; i += 64) s_part[i] = part[2 * b0 + i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int b = 0; b < nb; ++b) { sum += s_part[2 * b]; if (s_part[2 * b + 1] > mx) mx = s_part[2 * b + 1]; }
+    }
+    if (threadIdx.x != 0) return;
     const double ref = ref_is_max ? mx : sum / n;
     levels[0] = (float)sqrt(ref / snr_lin / 2.0);
     levels[1] = scr_lin > 0.0 ? (float)(ref / scr_lin) : 0.f;
