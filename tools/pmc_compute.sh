@@ -11,7 +11,7 @@ cd $R
 for t in videosar echo; do f=$(find gpurun_out/pmc_compute/$t -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/pmc_compute/${t}_counters.csv; done
 python3 - <<'PY'
 import csv, collections, json
-for t, kern in (("videosar", ("tdbp_kernel", "echo_synth_kernel")), ("echo", ("echo_synth_kernel",))):
+for t, kern in (("videosar", ("tdbp_tile_kernel", "tdbp_kernel", "echo_synth_kernel")), ("echo", ("echo_synth_kernel",))):
     try:
         rows = list(csv.DictReader(open(f"gpurun_out/pmc_compute/{t}_counters.csv")))
     except OSError:
@@ -19,7 +19,7 @@ for t, kern in (("videosar", ("tdbp_kernel", "echo_synth_kernel")), ("echo", ("e
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         for k in kern:
-            if k in r["Kernel_Name"]:
+            if ("::" + k + "(") in r["Kernel_Name"]:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
     for k, d in out.items():

@@ -28,11 +28,12 @@ def main():
     with open(a.stats_csv) as fh:
         for row in csv.DictReader(fh):
             avg[row["Name"]] = float(row["AverageNs"]) * 1e-9
-    units = {"echo_synth_kernel": float(a.echo_targets) * a.pulses * a.samples, "tdbp_kernel": float(a.pulses) * a.nx * a.nx}
+    units = {"echo_synth_kernel": float(a.echo_targets) * a.pulses * a.samples, "tdbp_kernel": float(a.pulses) * a.nx * a.nx,
+             "tdbp_tile_kernel": float(a.pulses) * a.nx * a.nx}
     peak = isa["n_simd"] * isa["clock_hz"]
     out = {}
     for k, info in isa["kernels"].items():
-        name = next((n for n in avg if k in n), None)
+        name = next((n for n in avg if ("::" + k + "(") in n), None)
         if name is None:
             continue
         t = avg[name]
