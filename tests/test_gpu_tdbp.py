@@ -126,6 +126,26 @@ def test_tile_expansion_equals_exact_kernel(speed, heading, monkeypatch):
     assert rel_l2(tile, ref) < TOL and rel_l2(exact, ref) < TOL
 
 
+def test_range_compression_one_launch_equals_three(monkeypatch):
+    """SARX_TDBP_RC_FUSED=0 keeps the form of rounds 2-4 (copy-in, forward transform with the reference spectrum, inverse transform,
+    copy-out per overlap-save block) for A/B; the one-launch form (wrapped segment in, FFT . spectrum . IFFT in registers / LDS) must
+    give the same range-compressed pulses and image."""
+    import sarx
+    k = tb.batch_constants()
+    sc = tb.tdbp_scene(n_pulses=48, seed=8, k=k, speed=15.0, heading_deg=60.0, swath=300.0, n_targets=3)
+    raw = sc["raw"].astype(np.complex64)
+    args = (sc["pos"], sc["vel"], sc["t_start"], sc["v_tgt"], sc["t_vec"], sc["swath"])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SARX_TDBP_RC_FUSED", mode)
+        plan = sarx.TdbpPlan(sarx.default_context(), 48, sc["num_samples"], 24, 24, k)      # the switch is read when a plan is created
+        out[mode] = plan.focus(raw, *args)
+        plan.close()
+    assert rel_l2(out["1"], out["0"]) < 2e-6
+    ref = tb.tdbp(raw, sc["pos"], sc["vel"], sc["t_start"], sc["num_samples"], sc["v_tgt"], sc["t_vec"], sc["swath"], 24, 24, k)
+    assert rel_l2(out["1"], ref) < TOL
+
+
 def test_tdbp_errors():
     import sarx
     k = tb.scaled_constants()
